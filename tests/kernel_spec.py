@@ -1,0 +1,292 @@
+"""Plain-PyTorch fp32 statement of every kernel entry point (TEST INFRASTRUCTURE).
+
+``SpecKernels`` has the same methods as ``uda_clr_amd.kernels.HipKernels`` and states, with
+ordinary torch ops, exactly what each HIP kernel must compute.  It is used
+  * by the ``-m gpu`` tests as the per-kernel fp32 reference, and
+  * by the CPU tests to run the engine's orchestration (``uda_clr_amd.engine``) end to end
+    against the oracle without a GPU (the engine accepts any object with these methods; the
+    product only ever constructs ``HipKernels``).
+It is never imported from ``uda_clr_amd``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from uda_clr_amd.acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, round4
+
+
+def _apply_act(a, act):
+    if act == ACT_RELU:
+        return torch.relu(a)
+    if act == ACT_RELU6:
+        return torch.clamp(a, 0.0, 6.0)
+    return a
+
+
+def _act_grad(a, act):
+    if act == ACT_RELU:
+        return (a > 0).to(a.dtype)
+    if act == ACT_RELU6:
+        return ((a > 0) & (a < 6)).to(a.dtype)
+    return torch.ones_like(a)
+
+
+def transform(src: Act):
+    """[P, C] activated values u = act(x*scale+shift) * mask*mask_scale."""
+    u = src.x
+    if src.scale is not None:
+        u = u * src.scale + src.shift
+    u = _apply_act(u, src.act)
+    if src.mask is not None:
+        u = u * (src.mask.to(u.dtype) * src.mask_scale)
+    return u
+
+
+def _nchw(m, N, H, W):
+    return m.reshape(N, H, W, m.shape[1]).permute(0, 3, 1, 2)
+
+
+def _rows(t):
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+
+
+def _src_index(o, scale, n_in):
+    real = scale * o.to(torch.float32)
+    i0 = real.to(torch.int64)
+    i1 = i0 + (i0 < n_in - 1).to(torch.int64)
+    l1 = real - i0.to(torch.float32)
+    return i0, i1, 1.0 - l1, l1
+
+
+def _bilinear_matrix(n_in, n_out, device):
+    """[n_out, n_in] interpolation matrix of align_corners=True bilinear resize."""
+    scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+    o = torch.arange(n_out, device=device)
+    i0, i1, l0, l1 = _src_index(o, torch.tensor(scale, dtype=torch.float32, device=device), n_in)
+    m = torch.zeros(n_out, n_in, device=device)
+    m[o, i0] += l0
+    m[o, i1] += l1
+    return m
+
+
+class SpecKernels:
+    name = "spec"
+
+    # ------------------------------------------------------------------ weight layouts
+    def relayout_ohwi(self, w):
+        O, I, kh, kw = w.shape
+        out = w.new_zeros(O, kh * kw, round4(I))
+        out[:, :, :I] = w.permute(0, 2, 3, 1).reshape(O, kh * kw, I)
+        return out
+
+    def relayout_dgrad(self, w):
+        O, I, kh, kw = w.shape
+        out = w.new_zeros(I, kh * kw, round4(O))
+        out[:, :, :O] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(I, kh * kw, O)
+        return out
+
+    def relayout_dw(self, w):
+        return w.reshape(w.shape[0], 9).t().contiguous()
+
+    # ------------------------------------------------------------------ dense conv (stride 1)
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None):
+        """out[p, co] = bias[co] + addend[p, co] + sum_{t, ci} u(p + off_t, ci) * w[co, t, ci];
+        ``w`` is [Cout, ksize^2, round4(Cin)]; zero padding dil*(ksize//2); stats (fp64 [2, Cout])
+        receives sum and sum of squares of the value before ``addend``."""
+        Cin, Cout = src.C, out.shape[1]
+        u = _nchw(transform(src), src.N, src.H, src.W)
+        w4 = w[:, :, :Cin].reshape(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
+        y = _rows(F.conv2d(u, w4, bias, 1, dil * (ksize // 2), dil))
+        if stats is not None:
+            stats[0] = y.double().sum(0)
+            stats[1] = (y.double() ** 2).sum(0)
+        if addend is not None:
+            y = y + addend
+        out.copy_(y)
+
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw):
+        """dw[co, ci, kh, kw] = sum_p dy[p, co] * u(p + off_t, ci)   (OIHW result)."""
+        u = _nchw(transform(src), src.N, src.H, src.W)
+        g = _nchw(dy, src.N, src.H, src.W)
+        pad = dil * (ksize // 2)
+        res = torch.nn.grad.conv2d_weight(u, dw.shape, g, 1, pad, dil)
+        dw.copy_(res)
+
+    # ------------------------------------------------------------------ depthwise 3x3
+    def _dw_input(self, src, dil, border_mode):
+        u = _nchw(transform(src), src.N, src.H, src.W)
+        up = F.pad(u, (dil, dil, dil, dil))
+        if border_mode == 1:          # quirk Q1: border holds act(shift) instead of 0
+            b = _apply_act(src.shift, src.act).view(1, -1, 1, 1)
+            m = F.pad(torch.zeros_like(u[:, :1]), (dil, dil, dil, dil), value=1.0)
+            up = up + b * m
+        return up
+
+    def dwconv_fwd(self, src: Act, w9c, stride, dil, border_mode, out, stats=None):
+        C = src.C
+        up = self._dw_input(src, dil, border_mode)
+        y = _rows(F.conv2d(up, w9c.t().reshape(C, 1, 3, 3), None, stride, 0, dil, C))
+        if stats is not None:
+            stats[0] = y.double().sum(0)
+            stats[1] = (y.double() ** 2).sum(0)
+        out.copy_(y)
+
+    def dwconv_dgrad(self, dy, w9c, stride, dil, N, H, W, out):
+        """Gradient w.r.t. the INTERIOR H x W positions of the padded depthwise input."""
+        C = dy.shape[1]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        g = _nchw(dy, N, Ho, Wo)
+        full = torch.nn.grad.conv2d_input((N, C, H + 2 * dil, W + 2 * dil), w9c.t().reshape(C, 1, 3, 3),
+                                          g, stride, 0, dil, C)
+        out.copy_(_rows(full[:, :, dil:dil + H, dil:dil + W]))
+
+    def dwconv_wgrad(self, src: Act, dy, stride, dil, border_mode, dw):
+        C = src.C
+        Ho, Wo = (src.H - 1) // stride + 1, (src.W - 1) // stride + 1
+        up = self._dw_input(src, dil, border_mode)
+        g = _nchw(dy, src.N, Ho, Wo)
+        dw.copy_(torch.nn.grad.conv2d_weight(up, (C, 1, 3, 3), g, stride, 0, dil, C))
+
+    # ------------------------------------------------------------------ stem 3x3 s2 p1, NCHW in
+    def stem_fwd(self, x, w, out, stats=None):
+        y = _rows(F.conv2d(x, w, None, 2, 1))
+        if stats is not None:
+            stats[0] = y.double().sum(0)
+            stats[1] = (y.double() ** 2).sum(0)
+        out.copy_(y)
+
+    def stem_wgrad(self, x, dy, dw):
+        N, _, H, W = x.shape
+        g = _nchw(dy, N, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+        dw.copy_(torch.nn.grad.conv2d_weight(x, dw.shape, g, 2, 1))
+
+    # ------------------------------------------------------------------ batch norm pieces
+    def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps,
+                    scale, shift, mean, invstd):
+        """Training BN coefficients from (sum, sumsq) over ``count`` elements; updates the running
+        statistics exactly like F.batch_norm (unbiased variance into running_var)."""
+        m = stats[0] / count
+        var = (stats[1] / count - m * m).clamp_min(0.0)
+        istd = 1.0 / torch.sqrt(var + eps)
+        mean.copy_(m.float())
+        invstd.copy_(istd.float())
+        sc = gamma.double() * istd
+        scale.copy_(sc.float())
+        shift.copy_((beta.double() - m * sc).float())
+        rmean.mul_(1 - momentum).add_(momentum * m.float())
+        rvar.mul_(1 - momentum).add_(momentum * (var * (count / max(count - 1.0, 1.0))).float())
+
+    def bn_eval_coeffs(self, gamma, beta, rmean, rvar, eps, scale, shift):
+        sc = gamma.double() / torch.sqrt(rvar.double() + eps)
+        scale.copy_(sc.float())
+        shift.copy_((beta.double() - rmean.double() * sc).float())
+
+    def bn_apply(self, src: Act, out, residual=None):
+        u = transform(src)
+        if residual is not None:
+            u = u + residual
+        out.copy_(u)
+
+    def colstats(self, x, stats):
+        stats[0] = x.double().sum(0)
+        stats[1] = (x.double() ** 2).sum(0)
+
+    def bnbwd_reduce(self, dU, y: Act, sums):
+        """y carries (x, scale, shift, act, mask, bn.mean/invstd).  g = dU * mask*ms * act'(a);
+        sums (fp64 [3, C]) = (sum g, sum g*xhat, sum dU)."""
+        a = y.x * y.scale + y.shift
+        g = dU * _act_grad(a, y.act)
+        if y.mask is not None:
+            g = g * (y.mask.to(g.dtype) * y.mask_scale)
+        xhat = (y.x - y.bn.mean) * y.bn.invstd
+        sums[0] = g.double().sum(0)
+        sums[1] = (g.double() * xhat.double()).sum(0)
+        sums[2] = dU.double().sum(0)
+
+    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
+        """Adds the border term of quirk Q1 when y.bn.q1_border, then c1 = sum g / n,
+        c2 = sum g*xhat / n, dgamma = sum g*xhat, dbeta = sum g."""
+        sg, sgx = sums[0].clone(), sums[1].clone()
+        if y.bn.q1_border:
+            sh = y.shift.double()
+            gate = torch.ones_like(sh) if y.act == ACT_NONE else (
+                (sh > 0).double() if y.act == ACT_RELU else ((sh > 0) & (sh < 6)).double())
+            gb = -sums[2] * gate
+            sg = sg + gb
+            sgx = sgx + gb * (-y.bn.mean.double() * y.bn.invstd.double())
+        c1.copy_((sg / y.bn.count).float())
+        c2.copy_((sgx / y.bn.count).float())
+        dgamma.copy_(sgx.float())
+        dbeta.copy_(sg.float())
+
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out):
+        a = y.x * y.scale + y.shift
+        g = dU * _act_grad(a, y.act)
+        if y.mask is not None:
+            g = g * (y.mask.to(g.dtype) * y.mask_scale)
+        xhat = (y.x - y.bn.mean) * y.bn.invstd
+        out.copy_(y.scale * (g - c1 - xhat * c2))
+
+    def act_bwd(self, dU, y: Act, out):
+        """Backward of the pending transform when BN is frozen/absent: out = dU*mask*act'(a)*scale."""
+        a = y.x if y.scale is None else y.x * y.scale + y.shift
+        g = dU * _act_grad(a, y.act)
+        if y.mask is not None:
+            g = g * (y.mask.to(g.dtype) * y.mask_scale)
+        if y.scale is not None:
+            g = g * y.scale
+        out.copy_(g)
+
+    # ------------------------------------------------------------------ resampling / pooling
+    def upsample_fwd(self, x, N, h, w, out, H, W):
+        """Bilinear align_corners=True, NHWC [N*h*w, C] -> NHWC [N*H*W, C]."""
+        mh, mw = _bilinear_matrix(h, H, x.device), _bilinear_matrix(w, W, x.device)
+        t = x.reshape(N, h, w, -1)
+        t = torch.einsum("Hh,nhwc->nHwc", mh, t)
+        t = torch.einsum("Ww,nHwc->nHWc", mw, t)
+        out.copy_(t.reshape(N * H * W, -1))
+
+    def upsample_bwd(self, dout, N, H, W, dx, h, w):
+        mh, mw = _bilinear_matrix(h, H, dout.device), _bilinear_matrix(w, W, dout.device)
+        t = dout.reshape(N, H, W, -1)
+        t = torch.einsum("Hh,nHWc->nhWc", mh, t)
+        t = torch.einsum("Ww,nhWc->nhwc", mw, t)
+        dx.copy_(t.reshape(N * h * w, -1))
+
+    def head_upsample_fwd(self, x, N, h, w, out):
+        """NHWC [N*h*w, C<=2] -> contiguous NCHW [N, C, H, W] (bilinear, align_corners)."""
+        H, W = out.shape[2], out.shape[3]
+        mh, mw = _bilinear_matrix(h, H, x.device), _bilinear_matrix(w, W, x.device)
+        t = x.reshape(N, h, w, -1)
+        out.copy_(torch.einsum("Hh,Ww,nhwc->ncHW", mh, mw, t))
+
+    def head_upsample_bwd(self, dout, dx, N, h, w, accumulate=False):
+        H, W = dout.shape[2], dout.shape[3]
+        mh, mw = _bilinear_matrix(h, H, dout.device), _bilinear_matrix(w, W, dout.device)
+        t = torch.einsum("Hh,Ww,ncHW->nhwc", mh, mw, dout).reshape(N * h * w, -1)
+        if accumulate:
+            dx.add_(t)
+        else:
+            dx.copy_(t)
+
+    def gap_fwd(self, x, N, out, scale):
+        """out[n, c] = scale * sum over the image's pixels of x."""
+        out.copy_(x.reshape(N, -1, x.shape[1]).sum(1) * scale)
+
+    def broadcast_rows(self, g, N, out, scale, addend=None):
+        """out[p, c] = addend[p, c] + scale * g[n(p), c]."""
+        P = out.shape[0]
+        t = (g * scale).repeat_interleave(P // N, dim=0)
+        if addend is not None:
+            t = t + addend
+        out.copy_(t)
+
+    def colsum(self, x, out):
+        out.copy_(x.double().sum(0).float())
+
+    def dropout_mask(self, mask, p, seed, offset):
+        """Bernoulli(1-p) keep-mask (uint8).  The bit stream is implementation-defined (Philox on
+        the device); parity tests inject masks instead of comparing streams."""
+        g = torch.Generator(device="cpu").manual_seed(int(seed) * 1000003 + int(offset))
+        mask.copy_((torch.rand(mask.shape, generator=g) >= p).to(torch.uint8).to(mask.device))

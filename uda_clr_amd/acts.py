@@ -1,0 +1,80 @@
+"""NHWC activation descriptors shared by the engine and the kernel bindings.
+
+Every activation of the generator lives in HBM as a 2-D ``[P, ld]`` fp32 matrix
+(P = N*H*W pixels, channels fastest, ``ld`` a multiple of 4 floats so every pixel
+row is 16-byte aligned).  Channel windows of one buffer replace the reference's
+``torch.cat`` calls (aspp.py:72, decoder.py:51,53).
+
+``Act`` additionally carries the *pending* per-channel transform that the
+consumer kernel applies while loading (training-mode BN cannot be folded into the
+producer because its statistics need the whole batch):
+
+    u[p, c] = act(x[p, c] * scale[c] + shift[c]) * (mask[p, c] * mask_scale)
+
+so a conv output is written once (raw) and read once (by its consumer).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+
+def round4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+@dataclass
+class BNRec:
+    """What BN backward needs about one normalisation (training mode)."""
+    key: str                       # state-dict prefix, e.g. 'aspp.bn1'
+    mean: torch.Tensor             # [C] batch mean
+    invstd: torch.Tensor           # [C] 1/sqrt(var+eps)
+    count: float                   # elements per channel the statistics were taken over
+    q1_border: bool = False        # statistics include the zero border of quirk Q1
+
+
+@dataclass
+class Act:
+    x: torch.Tensor                # [P, C] view, stride (ld, 1)
+    N: int
+    H: int
+    W: int
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    act: int = ACT_NONE
+    mask: Optional[torch.Tensor] = None     # uint8 [P, C] view (1 = keep)
+    mask_scale: float = 1.0
+    bn: Optional[BNRec] = None
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def C(self) -> int:
+        return self.x.shape[1]
+
+    @property
+    def P(self) -> int:
+        return self.x.shape[0]
+
+    @property
+    def lazy(self) -> bool:
+        return self.scale is not None or self.mask is not None or self.act != ACT_NONE
+
+    def check(self):
+        assert self.x.dim() == 2 and self.x.stride(1) == 1, "activation must be a [P, C] row-major view"
+        assert self.x.shape[0] == self.N * self.H * self.W
+        assert self.x.stride(0) % 4 == 0 and self.x.stride(0) >= round4(self.C)
+        assert self.x.data_ptr() % 16 == 0
+        if self.mask is not None:
+            assert self.mask.dtype == torch.uint8 and self.mask.shape == self.x.shape
+            assert self.mask.stride(1) == 1 and self.mask.stride(0) % 4 == 0
+        return self
+
+
+def nchw_view(x2d: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
+    """Logical [N, C, H, W] view (channels-last strides) of a [P, C] NHWC matrix."""
+    ld, C = x2d.stride(0), x2d.shape[1]
+    return x2d.as_strided((N, C, H, W), (H * W * ld, 1, W * ld, ld), x2d.storage_offset())

@@ -1,0 +1,435 @@
+"""Execution plan of the DeepLabV3+/MobileNetV2 generator on the HIP kernels.
+
+The whole generator is ONE autograd node (``networks.deeplabv3._GeneratorFn``): this module runs
+its forward as a fixed sequence of kernel launches on NHWC buffers and its backward as the
+hand-written reverse sequence, so no per-op autograd bookkeeping, no ``torch.cat`` and no
+separate BN / ReLU / dropout passes exist on the hot path.
+
+Reference behaviour reproduced (file:line in /root/reference):
+  networks/deeplabv3.py:32-41            7-tuple outputs
+  networks/backbone/mobilenet.py:61-67   quirk Q1 - the block input is zero-padded BEFORE the
+                                         1x1 expand conv, so the expand BN's statistics run over
+                                         (H+2d)(W+2d) positions and the depthwise conv sees
+                                         relu6(shift) on its border
+  networks/aspp.py:65-78, networks/decoder.py:45-56
+
+Fusion scheme ("kernels"): every conv writes its raw output once and accumulates the
+per-channel (sum, sum^2) for BN in its epilogue; the BN affine + ReLU/ReLU6 + dropout mask are
+applied by the CONSUMER while it loads its operand tile.
+
+``kernels`` is the binding object (``uda_clr_amd.kernels.HipKernels`` in the product; the tests
+also drive this file with their fp32 torch statement of the same entry points).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, BNRec, nchw_view, round4
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# (t, c, n, s) rows of the MobileNetV2 table (mobilenet.py:77-86)
+_MBV2 = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1),
+         (6, 160, 3, 2), (6, 320, 1, 1))
+
+DROPOUT = {"aspp.dropout": 0.5, "decoder.last_conv_boundary.3": 0.5,
+           "decoder.last_conv_boundary.7": 0.1, "decoder.last_conv.2": 0.1}
+
+
+def block_plan(output_stride: int = 16):
+    """[(inp, oup, stride, dilation, expand)] per inverted-residual block (mobilenet.py:88-111)."""
+    plan, inp, cur, rate = [], 32, 2, 1
+    for t, c, n, s in _MBV2:
+        if cur == output_stride:
+            stride, dil = 1, rate
+            rate *= s
+        else:
+            stride, dil = s, 1
+            cur *= s
+        for i in range(n):
+            plan.append((inp, c, stride if i == 0 else 1, dil, t))
+            inp = c
+    return plan
+
+
+def _rows(g: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW gradient -> [P, C] rows (zero-copy when it already is channels-last)."""
+    n, c, h, w = g.shape
+    return g.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+class _Ctx:
+    __slots__ = ("S", "N", "dims", "w_cache", "params", "x")
+
+    def __init__(self):
+        self.S = {}
+        self.w_cache = {}
+
+
+class GeneratorEngine:
+    def __init__(self, kernels, output_stride: int = 16, seed: int = 1337):
+        self.K = kernels
+        self.os = output_stride
+        self.blocks = block_plan(output_stride)
+        self.dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
+        self.seed = seed
+        self.rng_offset = 0
+
+    # ------------------------------------------------------------------ small helpers
+    @staticmethod
+    def _empty(x, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=x.device)
+
+    def _buf(self, x, P, C):
+        """[P, C] view of a fresh [P, round4(C)] buffer."""
+        return self._empty(x, P, round4(C))[:, :C]
+
+    def _stats(self, x, C, training):
+        return torch.zeros(2, C, dtype=torch.float64, device=x.device) if training else None
+
+    def _w(self, ctx, key, kind):
+        ck = (key, kind)
+        if ck not in ctx.w_cache:
+            w = ctx.params[key]
+            ctx.w_cache[ck] = {"ohwi": self.K.relayout_ohwi, "dgrad": self.K.relayout_dgrad,
+                               "dw": self.K.relayout_dw}[kind](w)
+        return ctx.w_cache[ck]
+
+    def _bn(self, ctx, prefix, stats, count, training, scale, shift, mean=None, invstd=None,
+            q1=False) -> Optional[BNRec]:
+        p = ctx.params
+        g, b = p[prefix + ".weight"], p[prefix + ".bias"]
+        rm, rv = p[prefix + ".running_mean"], p[prefix + ".running_var"]
+        if training:
+            if count <= 1:
+                raise ValueError("Expected more than 1 value per channel when training (%s)" % prefix)
+            self.K.bn_finalize(stats, float(count), g, b, rm, rv, BN_MOMENTUM, BN_EPS,
+                               scale, shift, mean, invstd)
+            nbt = p.get(prefix + ".num_batches_tracked")
+            if nbt is not None:
+                nbt += 1
+            return BNRec(prefix, mean, invstd, float(count), q1)
+        self.K.bn_eval_coeffs(g, b, rm, rv, BN_EPS, scale, shift)
+        return None
+
+    def _bn_act(self, ctx, prefix, y, N, H, W, stats, count, training, act, mask=None,
+                mask_scale=1.0, q1=False) -> Act:
+        C = y.shape[1]
+        coef = self._empty(y, 4, C)
+        rec = self._bn(ctx, prefix, stats, count, training, coef[0], coef[1], coef[2], coef[3], q1)
+        return Act(y, N, H, W, coef[0], coef[1], act, mask, mask_scale, rec)
+
+    def _mask(self, x, name, P, C, N, H, W, training, masks):
+        if not training:
+            return None, 1.0
+        p = DROPOUT[name]
+        m = torch.empty((P, round4(C)), dtype=torch.uint8, device=x.device)[:, :C]
+        if masks is not None:
+            m.copy_(_rows(masks[name].to(x.device)))
+        else:
+            self.K.dropout_mask(m, p, self.seed, self.rng_offset)
+            self.rng_offset += 1
+        return m, 1.0 / (1.0 - p)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, params: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
+                need_grad: bool, masks=None):
+        K = self.K
+        ctx = _Ctx()
+        ctx.params, ctx.x = params, x
+        S = ctx.S
+        N, _, Hin, Win = x.shape
+        if Hin % 16 or Win % 16:
+            raise ValueError("input height/width must be multiples of 16, got %dx%d" % (Hin, Win))
+        ctx.N = N
+        # ---- stem (mobilenet.py:8-13)
+        H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+        y0 = self._buf(x, N * H * W, 32)
+        st = self._stats(x, 32, training)
+        K.stem_fwd(x, params["backbone.features.0.0.weight"], y0, st)
+        a = self._bn_act(ctx, "backbone.features.0.1", y0, N, H, W, st, N * H * W, training, ACT_RELU6)
+        S["stem"] = a
+        # ---- inverted residual blocks (mobilenet.py:25-67)
+        recs = []
+        low = None
+        for i, (inp, oup, stride, dil, t) in enumerate(self.blocks, start=1):
+            pre = "backbone.features.%d" % i
+            zin, H, W = a, a.H, a.W
+            hid = inp * t
+            if t != 1:
+                ye = self._buf(x, N * H * W, hid)
+                st = self._stats(x, hid, training)
+                K.conv(zin, self._w(ctx, pre + ".conv.0.weight", "ohwi"), 1, 1, ye, stats=st)
+                cnt = N * (H + 2 * dil) * (W + 2 * dil)          # quirk Q1
+                e = self._bn_act(ctx, pre + ".conv.1", ye, N, H, W, st, cnt, training, ACT_RELU6, q1=True)
+                border, kd, kdb, kp, kpb = 1, ".conv.3", ".conv.4", ".conv.6", ".conv.7"
+            else:
+                e, border, kd, kdb, kp, kpb = zin, 0, ".conv.0", ".conv.1", ".conv.3", ".conv.4"
+            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+            Po = N * Ho * Wo
+            yd = self._buf(x, Po, hid)
+            st = self._stats(x, hid, training)
+            K.dwconv_fwd(e, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, border, yd, st)
+            d = self._bn_act(ctx, pre + kdb, yd, N, Ho, Wo, st, Po, training, ACT_RELU6)
+            yp = self._buf(x, Po, oup)
+            st = self._stats(x, oup, training)
+            K.conv(d, self._w(ctx, pre + kp + ".weight", "ohwi"), 1, 1, yp, stats=st)
+            pb = self._bn_act(ctx, pre + kpb, yp, N, Ho, Wo, st, Po, training, ACT_NONE)
+            use_res = stride == 1 and inp == oup
+            z = self._buf(x, Po, oup)
+            K.bn_apply(pb, z, zin.x if use_res else None)
+            a = Act(z, N, Ho, Wo)
+            recs.append(dict(pre=pre, t=t, stride=stride, dil=dil, zin=zin, e=e, d=d, pb=pb,
+                             use_res=use_res, border=border, keys=(kd, kdb, kp, kpb)))
+            if i == 3:
+                low = a
+        S["blocks"] = recs
+        # ---- ASPP (aspp.py:65-78): branches write channel windows of one [P, 1280] buffer
+        a17, H16, W16 = a, a.H, a.W
+        P16 = N * H16 * W16
+        cat = self._empty(x, P16, 1280)
+        coef = self._empty(x, 4, 1280)
+        brecs = []
+        for j, dl in enumerate(self.dils, start=1):
+            sl = slice(256 * (j - 1), 256 * j)
+            st = self._stats(x, 256, training)
+            key = "aspp.aspp%d" % j
+            K.conv(a17, self._w(ctx, key + ".atrous_conv.weight", "ohwi"), 1 if j == 1 else 3, dl,
+                   cat[:, sl], stats=st)
+            brecs.append(self._bn(ctx, key + ".bn", st, P16, training, coef[0, sl], coef[1, sl],
+                                  coef[2, sl], coef[3, sl]))
+        gp = self._empty(x, N, 320)
+        K.gap_fwd(a17.x, N, gp, 1.0 / (H16 * W16))
+        yg = self._empty(x, N, 256)
+        st = self._stats(x, 256, training)
+        gpa = Act(gp, N, 1, 1)
+        K.conv(gpa, self._w(ctx, "aspp.global_avg_pool.1.weight", "ohwi"), 1, 1, yg, stats=st)
+        sl = slice(1024, 1280)
+        grec = self._bn(ctx, "aspp.global_avg_pool.2", st, N, training, coef[0, sl], coef[1, sl],
+                        coef[2, sl], coef[3, sl])
+        K.broadcast_rows(yg, N, cat[:, sl], 1.0)
+        catA = Act(cat, N, H16, W16, coef[0], coef[1], ACT_RELU)
+        y1 = self._empty(x, P16, 256)
+        st = self._stats(x, 256, training)
+        K.conv(catA, self._w(ctx, "aspp.conv1.weight", "ohwi"), 1, 1, y1, stats=st)
+        m, ms = self._mask(x, "aspp.dropout", P16, 256, N, H16, W16, training, masks)
+        fa = self._bn_act(ctx, "aspp.bn1", y1, N, H16, W16, st, P16, training, ACT_RELU, m, ms)
+        feature = self._empty(x, P16, 256)
+        K.bn_apply(fa, feature, None)
+        S["aspp"] = dict(a17=a17, cat=cat, coef=coef, brecs=brecs, grec=grec, gpa=gpa, yg=yg,
+                         catA=catA, fa=fa)
+        # ---- decoder (decoder.py:45-56): x_bu_feature / x_feature / boundary share one buffer
+        H4, W4 = low.H, low.W
+        P4 = N * H4 * W4
+        xf = self._empty(x, P4, 308)
+        ylo = self._empty(x, P4, 48)
+        st = self._stats(x, 48, training)
+        K.conv(low, self._w(ctx, "decoder.conv1.weight", "ohwi"), 1, 1, ylo, stats=st)
+        lo = self._bn_act(ctx, "decoder.bn1", ylo, N, H4, W4, st, P4, training, ACT_RELU)
+        K.bn_apply(lo, xf[:, 256:304], None)
+        K.upsample_fwd(feature, N, H16, W16, xf[:, 0:256], H4, W4)
+        xbu = Act(xf[:, :304], N, H4, W4)
+        yb1 = self._empty(x, P4, 256)
+        st = self._stats(x, 256, training)
+        K.conv(xbu, self._w(ctx, "decoder.last_conv_boundary.0.weight", "ohwi"), 3, 1, yb1, stats=st)
+        m, ms = self._mask(x, "decoder.last_conv_boundary.3", P4, 256, N, H4, W4, training, masks)
+        b1 = self._bn_act(ctx, "decoder.last_conv_boundary.1", yb1, N, H4, W4, st, P4, training,
+                          ACT_RELU, m, ms)
+        yb2 = self._empty(x, P4, 256)
+        st = self._stats(x, 256, training)
+        K.conv(b1, self._w(ctx, "decoder.last_conv_boundary.4.weight", "ohwi"), 3, 1, yb2, stats=st)
+        m, ms = self._mask(x, "decoder.last_conv_boundary.7", P4, 256, N, H4, W4, training, masks)
+        b2 = self._bn_act(ctx, "decoder.last_conv_boundary.5", yb2, N, H4, W4, st, P4, training,
+                          ACT_RELU, m, ms)
+        K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1,
+               xf[:, 304:305], bias=params["decoder.last_conv_boundary.8.bias"])
+        st = self._stats(x, 305, training)
+        if training:
+            K.colstats(xf[:, :305], st)
+        m, ms = self._mask(x, "decoder.last_conv.2", P4, 305, N, H4, W4, training, masks)
+        sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N, H4, W4, st, P4, training,
+                          ACT_RELU, m, ms)
+        x1b = self._buf(x, P4, 2)
+        K.conv(sa, self._w(ctx, "decoder.last_conv.3.weight", "ohwi"), 1, 1, x1b,
+               bias=params["decoder.last_conv.3.bias"])
+        x1 = self._empty(x, N, 2, Hin, Win)
+        x2 = self._empty(x, N, 1, Hin, Win)
+        K.head_upsample_fwd(x1b, N, H4, W4, x1)
+        K.head_upsample_fwd(xf[:, 304:305], N, H4, W4, x2)
+        S["dec"] = dict(low=low, xf=xf, lo=lo, xbu=xbu, b1=b1, b2=b2, sa=sa, x1b=x1b)
+        ctx.dims = (N, Hin, Win, H16, W16, H4, W4)
+        outs = (x1, x2, nchw_view(feature, N, H16, W16), nchw_view(xf[:, :304], N, H4, W4),
+                nchw_view(xf[:, :305], N, H4, W4), nchw_view(x1b, N, H4, W4),
+                nchw_view(xf[:, 304:305], N, H4, W4))
+        return outs, (ctx if need_grad else None)
+
+    # ------------------------------------------------------------------ backward pieces
+    def _bn_backward(self, ctx, G, y: Act, dU, out=None, addend=None, keys=None):
+        """dU: gradient w.r.t. the activated values of ``y``.  Writes the gradient w.r.t. the raw
+        tensor y.x into ``out`` (default: in place over dU) and the BN parameter gradients into G."""
+        K = self.K
+        if y.bn is None:
+            raise NotImplementedError("backward through frozen (eval-mode) BatchNorm is not built yet")
+        C = y.C
+        sums = torch.zeros(3, C, dtype=torch.float64, device=dU.device)
+        K.bnbwd_reduce(dU, y, sums)
+        cg = self._empty(dU, 4, C)
+        K.bnbwd_finalize(sums, y, cg[0], cg[1], cg[2], cg[3])
+        out = dU if out is None else out
+        K.bnbwd_apply(dU, y, cg[0], cg[1], out, addend)
+        if keys is None:
+            keys = [(y.bn.key, slice(0, C))]
+        for key, sl in keys:
+            G[key + ".weight"] = cg[2, sl]
+            G[key + ".bias"] = cg[3, sl]
+        return out
+
+    def _wgrad(self, ctx, G, key, src: Act, dy, ksize, dil):
+        dw = torch.empty_like(ctx.params[key])
+        self.K.conv_wgrad(src, dy, ksize, dil, dw)
+        G[key] = dw
+
+    def _dgrad(self, ctx, key, dy, N, H, W, ksize, dil, out, addend=None):
+        self.K.conv(Act(dy, N, H, W), self._w(ctx, key, "dgrad"), ksize, dil, out, addend=addend)
+        return out
+
+    def _bias_grad(self, G, key, dy):
+        g = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+        self.K.colsum(dy, g)
+        G[key] = g
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, grads):
+        """grads: 7 optional tensors shaped like the forward outputs.  Returns {param key: grad}."""
+        K = self.K
+        gx1, gx2, gfeat, gxbu, gxf, gx1b, gx2b = grads
+        S, x = ctx.S, ctx.x
+        N, Hin, Win, H16, W16, H4, W4 = ctx.dims
+        P4, P16 = N * H4 * W4, N * H16 * W16
+        G: Dict[str, torch.Tensor] = {}
+        D = S["dec"]
+        xf = D["xf"]
+        # ---- heads (deeplabv3.py:39-40)
+        d_x1b = self._buf(x, P4, 2)
+        if gx1 is not None:
+            K.head_upsample_bwd(gx1.contiguous(), d_x1b, N, H4, W4, False)
+        else:
+            d_x1b.zero_()
+        if gx1b is not None:
+            d_x1b.add_(_rows(gx1b))
+        d_xf = torch.zeros(P4, 308, dtype=torch.float32, device=x.device)
+        if gxf is not None:
+            d_xf[:, :305].add_(_rows(gxf))
+        if gxbu is not None:
+            d_xf[:, :304].add_(_rows(gxbu))
+        if gx2b is not None:
+            d_xf[:, 304:305].add_(_rows(gx2b))
+        if gx2 is not None:
+            K.head_upsample_bwd(gx2.contiguous(), d_xf[:, 304:305], N, H4, W4, True)
+        # ---- decoder.last_conv: BN(305) -> ReLU -> Dropout -> 1x1 (decoder.py:23-32)
+        sa = D["sa"]
+        self._wgrad(ctx, G, "decoder.last_conv.3.weight", sa, d_x1b, 1, 1)
+        self._bias_grad(G, "decoder.last_conv.3.bias", d_x1b)
+        dU = self._buf(x, P4, 305)
+        self._dgrad(ctx, "decoder.last_conv.3.weight", d_x1b, N, H4, W4, 1, 1, dU)
+        self._bn_backward(ctx, G, sa, dU, out=d_xf[:, :305], addend=d_xf[:, :305])
+        # ---- boundary head (decoder.py:33-41)
+        b1, b2 = D["b1"], D["b2"]
+        d_x2b = d_xf[:, 304:305]
+        self._wgrad(ctx, G, "decoder.last_conv_boundary.8.weight", b2, d_x2b, 1, 1)
+        self._bias_grad(G, "decoder.last_conv_boundary.8.bias", d_x2b)
+        dU2 = self._empty(x, P4, 256)
+        self._dgrad(ctx, "decoder.last_conv_boundary.8.weight", d_x2b, N, H4, W4, 1, 1, dU2)
+        dy2 = self._bn_backward(ctx, G, b2, dU2)
+        self._wgrad(ctx, G, "decoder.last_conv_boundary.4.weight", b1, dy2, 3, 1)
+        dU1 = self._empty(x, P4, 256)
+        self._dgrad(ctx, "decoder.last_conv_boundary.4.weight", dy2, N, H4, W4, 3, 1, dU1)
+        del dU2, dy2
+        dy1 = self._bn_backward(ctx, G, b1, dU1)
+        self._wgrad(ctx, G, "decoder.last_conv_boundary.0.weight", D["xbu"], dy1, 3, 1)
+        self._dgrad(ctx, "decoder.last_conv_boundary.0.weight", dy1, N, H4, W4, 3, 1,
+                    d_xf[:, :304], addend=d_xf[:, :304])
+        del dU1, dy1
+        # ---- low-level branch (decoder.py:46-48)
+        lo, low = D["lo"], D["low"]
+        dylo = self._empty(x, P4, 48)
+        self._bn_backward(ctx, G, lo, d_xf[:, 256:304], out=dylo)
+        self._wgrad(ctx, G, "decoder.conv1.weight", low, dylo, 1, 1)
+        d_low = self._buf(x, P4, 24)
+        self._dgrad(ctx, "decoder.conv1.weight", dylo, N, H4, W4, 1, 1, d_low)
+        # ---- bilinear x4 of the ASPP output (decoder.py:50)
+        d_feat = self._empty(x, P16, 256)
+        K.upsample_bwd(d_xf[:, 0:256], N, H4, W4, d_feat, H16, W16)
+        del d_xf
+        if gfeat is not None:
+            d_feat.add_(_rows(gfeat))
+        # ---- ASPP (aspp.py:65-78)
+        A = S["aspp"]
+        dy1a = self._bn_backward(ctx, G, A["fa"], d_feat)
+        self._wgrad(ctx, G, "aspp.conv1.weight", A["catA"], dy1a, 1, 1)
+        dUc = self._empty(x, P16, 1280)
+        self._dgrad(ctx, "aspp.conv1.weight", dy1a, N, H16, W16, 1, 1, dUc)
+        coef, cat = A["coef"], A["cat"]
+        c4 = Act(cat[:, :1024], N, H16, W16, coef[0, :1024], coef[1, :1024], ACT_RELU, None, 1.0,
+                 BNRec("aspp", coef[2, :1024], coef[3, :1024], float(P16)))
+        keys = [("aspp.aspp%d.bn" % j, slice(256 * (j - 1), 256 * j)) for j in (1, 2, 3, 4)]
+        dyc = self._bn_backward(ctx, G, c4, dUc[:, :1024], keys=keys)
+        dUg = self._empty(x, N, 256)
+        K.gap_fwd(dUc[:, 1024:1280], N, dUg, 1.0)
+        yga = Act(A["yg"], N, 1, 1, coef[0, 1024:], coef[1, 1024:], ACT_RELU, None, 1.0,
+                  BNRec("aspp.global_avg_pool.2", coef[2, 1024:], coef[3, 1024:], float(N)))
+        dyg = self._bn_backward(ctx, G, yga, dUg)
+        self._wgrad(ctx, G, "aspp.global_avg_pool.1.weight", A["gpa"], dyg, 1, 1)
+        d_gp = self._empty(x, N, 320)
+        self._dgrad(ctx, "aspp.global_avg_pool.1.weight", dyg, N, 1, 1, 1, 1, d_gp)
+        d_a = self._empty(x, P16, 320)
+        K.broadcast_rows(d_gp, N, d_a, 1.0 / (H16 * W16), None)
+        a17 = A["a17"]
+        for j, dl in enumerate(self.dils, start=1):
+            key = "aspp.aspp%d.atrous_conv.weight" % j
+            sl = slice(256 * (j - 1), 256 * j)
+            k = 1 if j == 1 else 3
+            self._wgrad(ctx, G, key, a17, dyc[:, sl], k, dl)
+            self._dgrad(ctx, key, dyc[:, sl], N, H16, W16, k, dl, d_a, addend=d_a)
+        del dUc, dyc
+        # ---- backbone, last block first (mobilenet.py:61-67)
+        d_z = d_a
+        dU_stem = None
+        for i in range(len(S["blocks"]), 0, -1):
+            r = S["blocks"][i - 1]
+            pre, t, stride, dil = r["pre"], r["t"], r["stride"], r["dil"]
+            kd, kdb, kp, kpb = r["keys"]
+            zin, e, d, pb = r["zin"], r["e"], r["d"], r["pb"]
+            No, Ho, Wo = d.N, d.H, d.W
+            Hi, Wi = zin.H, zin.W
+            dyp = self._buf(x, d.P, pb.C)
+            self._bn_backward(ctx, G, pb, d_z, out=dyp)
+            self._wgrad(ctx, G, pre + kp + ".weight", d, dyp, 1, 1)
+            dUd = self._buf(x, d.P, d.C)
+            self._dgrad(ctx, pre + kp + ".weight", dyp, No, Ho, Wo, 1, 1, dUd)
+            dyd = self._bn_backward(ctx, G, d, dUd)
+            dwg = torch.empty_like(ctx.params[pre + kd + ".weight"])
+            K.dwconv_wgrad(e, dyd, stride, dil, r["border"], dwg)
+            G[pre + kd + ".weight"] = dwg
+            dUe = self._buf(x, zin.P, d.C)
+            K.dwconv_dgrad(dyd, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, N, Hi, Wi, dUe)
+            del dUd, dyd, dyp
+            if t != 1:
+                dye = self._bn_backward(ctx, G, e, dUe)
+                self._wgrad(ctx, G, pre + ".conv.0.weight", zin, dye, 1, 1)
+                d_zin = self._buf(x, zin.P, zin.C)
+                addend = d_z if r["use_res"] else (d_low if i == 4 else None)
+                self._dgrad(ctx, pre + ".conv.0.weight", dye, N, Hi, Wi, 1, 1, d_zin, addend=addend)
+                d_z = d_zin
+                del dUe, dye
+            else:
+                dU_stem = dUe
+        # ---- stem (mobilenet.py:8-13); the image itself needs no gradient
+        dy0 = self._bn_backward(ctx, G, S["stem"], dU_stem)
+        dw0 = torch.empty_like(ctx.params["backbone.features.0.0.weight"])
+        K.stem_wgrad(x, dy0, dw0)
+        G["backbone.features.0.0.weight"] = dw0
+        return G

@@ -220,13 +220,17 @@ class SpecKernels:
         dgamma.copy_(sgx.float())
         dbeta.copy_(sg.float())
 
-    def bnbwd_apply(self, dU, y: Act, c1, c2, out):
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None):
+        """out = addend + scale * (g - c1 - xhat * c2)   (may run in place over dU / addend)."""
         a = y.x * y.scale + y.shift
         g = dU * _act_grad(a, y.act)
         if y.mask is not None:
             g = g * (y.mask.to(g.dtype) * y.mask_scale)
         xhat = (y.x - y.bn.mean) * y.bn.invstd
-        out.copy_(y.scale * (g - c1 - xhat * c2))
+        r = y.scale * (g - c1 - xhat * c2)
+        if addend is not None:
+            r = r + addend
+        out.copy_(r)
 
     def act_bwd(self, dU, y: Act, out):
         """Backward of the pending transform when BN is frozen/absent: out = dU*mask*act'(a)*scale."""

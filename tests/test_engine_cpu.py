@@ -1,0 +1,112 @@
+"""CPU check of the ORCHESTRATION in uda_clr_amd.engine (launch order, buffer windows, the
+hand-written backward, quirk-Q1 bookkeeping): the engine is driven with the tests' fp32 torch
+statement of the kernel entry points (tests/kernel_spec.py) and compared with the oracle.
+The HIP kernels themselves are checked against the same statements in the -m gpu tests."""
+import pytest
+import torch
+
+from kernel_spec import SpecKernels
+from oracle import deeplab_ref, step_ref
+from uda_clr_amd.engine import GeneratorEngine
+from uda_clr_amd.networks.deeplabv3 import DeepLab
+
+NAMES = ("x1", "x2", "feature", "x_bu_feature", "x_feature", "x1_before", "x2_before")
+
+
+def _model(seed=1337):
+    torch.manual_seed(seed)
+    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16)
+    m._engine_override = GeneratorEngine(SpecKernels())
+    # perturb BN affine/running stats so that every term of the BN math is exercised
+    g = torch.Generator().manual_seed(5)
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        elif k.endswith("running_var"):
+            v.copy_(0.5 + torch.rand(v.shape, generator=g))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    return m
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("size", [64, 96])
+def test_eval_forward_matches_oracle(size):
+    m = _model().eval()
+    x = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        mine = m(x)
+        ref = deeplab_ref.deeplab_forward(deeplab_ref.canonical_state(m.state_dict()), x, training=False)
+    for n, a, b in zip(NAMES, mine, ref):
+        assert a.shape == b.shape, n
+        assert _rel(a, b) < 2e-4, (n, _rel(a, b))
+
+
+def test_train_forward_backward_matches_oracle():
+    m = _model().train()
+    B, S = 2, 64
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    tmap = (torch.rand(B, 2, S, S, generator=gen) > 0.5).float()
+    tbd = torch.rand(B, 1, S, S, generator=gen)
+    masks = deeplab_ref.draw_masks(B, S, S, gen)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    # extra heads so that every one of the 7 outputs receives a gradient
+    wf = [torch.randn(t, generator=gen) for t in (256, 304, 305, 2, 1)]
+
+    def total(outs):
+        x1, x2, feat, xbu, xf, x1b, x2b = outs
+        loss = step_ref.seg_loss(x1, x2, tmap, tbd)
+        for t, w in zip((feat, xbu, xf, x1b, x2b), wf):
+            loss = loss + 1e-2 * (t * w.view(1, -1, 1, 1)).pow(2).mean()
+        return loss
+
+    m.set_dropout_masks(masks)
+    outs = m(x)
+    loss = total(outs)
+    loss.backward()
+    osd = deeplab_ref.canonical_state(sd0, requires_grad=True)
+    ref = deeplab_ref.deeplab_forward(osd, x, training=True, masks=masks)
+    rloss = total(ref)
+    rloss.backward()
+    # fp64 run of the same oracle = ground truth; the fp32 oracle's own distance to it is the
+    # noise floor of this (tiny, ill-conditioned: BN over 2x4x4 samples) problem
+    o64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.clone())
+           for k, v in deeplab_ref.canonical_state(sd0, requires_grad=True).items()}
+    wf64 = [w.double() for w in wf]
+    r64 = deeplab_ref.deeplab_forward(o64, x.double(), training=True, masks=masks)
+    l64 = step_ref.seg_loss(r64[0], r64[1], tmap.double(), tbd.double())
+    for t, w in zip(r64[2:], wf64):
+        l64 = l64 + 1e-2 * (t * w.view(1, -1, 1, 1)).pow(2).mean()
+    l64.backward()
+    for n, a, b in zip(NAMES, outs, ref):
+        assert _rel(a, b) < 2e-4, (n, _rel(a, b))
+    assert abs(loss.item() - rloss.item()) < 1e-5 * abs(rloss.item())
+    live = m._flat_state()
+    worst = ("", 0.0)
+    for k in deeplab_ref.parameter_keys(osd):
+        g = live[k].grad
+        assert g is not None, k
+        e, floor = _rel(g, o64[k].grad), _rel(osd[k].grad, o64[k].grad)
+        worst = max(worst, (k, e / max(floor, 1e-4)), key=lambda t: t[1])
+        assert e < 3.0 * floor + 1e-4, (k, e, floor)
+    print("worst grad rel err", worst)
+    for k, v in osd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert _rel(live[k], v) < 5e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(live[k]) == int(v) == 1
+
+
+def test_no_grad_train_forward_updates_running_stats_only():
+    m = _model().train()
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        outs = m(x)
+    assert not outs[0].requires_grad
+    assert int(m.state_dict()["aspp.bn1.num_batches_tracked"]) == 1

@@ -1,0 +1,124 @@
+"""DeepLabV3+ generator - the drop-in for the reference's ``networks/deeplabv3.py``.
+
+Same constructor, same ``state_dict`` keys (675 entries incl. the aliased backbone slices), same
+seeded initialisation, same 7-tuple from ``forward`` (deeplabv3.py:32-41):
+
+    x1, x2, feature, x_bu_feature, x_feature, x1_before, x2_before
+
+but the whole forward/backward is ONE autograd node executed by ``uda_clr_amd.engine`` on the
+hand-written gfx950 kernels.  There is no CPU path: a CPU input (or a missing
+``libuda_clr_hip.so``) raises.
+"""
+import torch
+import torch.nn as nn
+
+from ..engine import GeneratorEngine
+from ._tree import Holder
+from .aspp import build_aspp
+from .backbone import build_backbone
+from .decoder import build_decoder
+
+__all__ = ["DeepLab"]
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, need_grad, keys, *tensors):
+        engine = module._engine_for(x)
+        params = module._flat_state()
+        masks, module._next_masks = module._next_masks, None
+        outs, ectx = engine.forward(params, x, module._bn_training(), need_grad, masks)
+        ctx.engine, ctx.ectx, ctx.keys = engine, ectx, keys
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if ctx.ectx is None:
+            raise RuntimeError("generator forward ran without gradient bookkeeping")
+        G = ctx.engine.backward(ctx.ectx, grads)
+        ctx.ectx = None
+        return (None, None, None, None) + tuple(G.get(k) for k in ctx.keys)
+
+
+class DeepLab(Holder):
+    def __init__(self, backbone='resnet', output_stride=16, num_classes=21,
+                 sync_bn=True, freeze_bn=False, method='prototype'):
+        super().__init__()
+        if not sync_bn:
+            raise NotImplementedError("TransNorm (--use_TN) is outside the built hot path (SURVEY.md 8f-3)")
+        if num_classes != 2:
+            raise NotImplementedError("the fused heads are built for num_classes=2 (cup, disc)")
+        BatchNorm = nn.BatchNorm2d
+        self.output_stride = output_stride
+        self.backbone = build_backbone(backbone, output_stride, BatchNorm)
+        self.aspp = build_aspp(backbone, output_stride, BatchNorm)
+        self.decoder = build_decoder(num_classes, backbone, method, BatchNorm)
+        self._engine = None
+        self._engine_override = None      # tests only: an engine bound to their torch kernel spec
+        self._next_masks = None           # tests only: injected dropout keep-masks for one forward
+        if freeze_bn:
+            self.freeze_bn()
+
+    # ---------------------------------------------------------------- reference API
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def _lr_params(self, roots):
+        for root in roots:
+            for m in root.modules():
+                if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                    for p in m.parameters(recurse=False):
+                        if p.requires_grad:
+                            yield p
+
+    def get_1x_lr_params(self):
+        return self._lr_params([self.backbone.features])
+
+    def get_10x_lr_params(self):
+        return self._lr_params([self.aspp, self.decoder])
+
+    # ---------------------------------------------------------------- engine plumbing
+    def set_dropout_masks(self, masks):
+        """Parity tests: keep-masks ({site: uint8 NCHW}) used by the next training forward."""
+        self._next_masks = masks
+
+    def _flat_state(self):
+        sd = {}
+        for name, mod in (("backbone.features", self.backbone.features), ("aspp", self.aspp),
+                          ("decoder", self.decoder)):
+            for k, v in mod.named_parameters(prefix=name):
+                sd[k] = v
+            for k, v in mod.named_buffers(prefix=name):
+                sd[k] = v
+        return sd
+
+    def _bn_training(self):
+        flags = {m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)}
+        if len(flags) != 1:
+            raise NotImplementedError("mixed train/eval BatchNorm layers are not built")
+        flag = flags.pop()
+        if flag != self.training:
+            raise NotImplementedError("freeze_bn while training (eval-mode BN backward) is not built yet")
+        return flag
+
+    def _engine_for(self, x):
+        if self._engine_override is not None:
+            return self._engine_override
+        if not x.is_cuda:
+            raise RuntimeError("uda_clr_amd.DeepLab computes only on the MI355X HIP kernels; got a "
+                               "%s tensor (there is no CPU fallback)" % x.device)
+        if self._engine is None:
+            from ..kernels import HipKernels
+            self._engine = GeneratorEngine(HipKernels(), self.output_stride)
+        return self._engine
+
+    def forward(self, input):
+        if input.dim() != 4 or input.shape[1] != 3:
+            raise ValueError("expected an [N, 3, H, W] image batch")
+        x = input.contiguous().float()
+        state = self._flat_state()
+        keys = tuple(k for k, v in state.items() if isinstance(v, nn.Parameter))
+        need_grad = torch.is_grad_enabled() and any(state[k].requires_grad for k in keys)
+        return _GeneratorFn.apply(self, x, need_grad, keys, *[state[k] for k in keys])

@@ -1,0 +1,161 @@
+/* libuda_clr_hip.so - C ABI of the MI355X (gfx950) kernels behind the UDA_CLR per-step hot path.
+ *
+ * The reference (fengweie/UDA_CLR) is pure Python/PyTorch: it has no FFI of its own.  Each entry
+ * point below replaces the ATen operator(s) that the cited reference line executes; the
+ * reference-side binding a maintainer would add is the ctypes stub in INTEGRATION.md
+ * (uda_clr_amd/kernels.py is that stub, grown into a class).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, a hipStream_t passed as void*; no C++/torch types.
+ *   - every function returns 0 on success, a negative code on failure and never throws;
+ *     uda_last_error() returns a thread-local message for the last failure.
+ *   - kernels never allocate: outputs and workspaces are caller-owned (PyTorch caching allocator);
+ *     workspace sizes come from the *_workspace_bytes queries.
+ *   - launches are asynchronous on `stream`; functions are re-entrant (no global mutable state).
+ *   - activations are NHWC fp32 matrices [P = N*H*W, ld] (channels fastest, ld % 4 == 0, base
+ *     16-byte aligned, at least round4(C) readable floats per row).  uda_src_t adds the pending
+ *     per-channel transform the consumer applies on load:
+ *         u[p,c] = act(x[p,c]*scale[c] + shift[c]) * (mask[p,c] * mask_scale)
+ */
+#ifndef UDA_CLR_HIP_H
+#define UDA_CLR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDA_ACT_NONE 0
+#define UDA_ACT_RELU 1
+#define UDA_ACT_RELU6 2
+
+typedef struct uda_src {
+    const float* x;       /* [P, ldx] */
+    int64_t ldx;
+    int32_t N, H, W, C;
+    const float* scale;   /* [C] or NULL (identity) */
+    const float* shift;   /* [C] or NULL */
+    int32_t act;          /* UDA_ACT_* */
+    int32_t _pad;
+    const uint8_t* mask;  /* [P, ldm] keep-mask (1 = keep) or NULL */
+    int64_t ldm;
+    float mask_scale;     /* 1/(1-p) */
+    float _pad2;
+} uda_src_t;
+
+const char* uda_last_error(void);
+int uda_version(void);
+
+/* ---- weight re-layouts (tiny; once per step).  torch layout OIHW in. */
+/* out[O][k*k][round4(I)] (zero padded)              - operand of uda_conv_fwd              */
+int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out, void* stream);
+/* out[I][k*k][round4(O)], taps flipped             - operand of uda_conv_fwd used as dgrad */
+int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* stream);
+/* depthwise [C][1][3][3] -> [9][C] */
+int uda_relayout_dw(const float* w, int C, float* out, void* stream);
+
+/* ---- dense stride-1 convolution as FP32-MFMA implicit GEMM (1x1 and 3x3, any dilation).
+ * Replaces F.conv2d at mobilenet.py:43,49,57, aspp.py:50-53,56,59, decoder.py:20,32,33,37,41 and,
+ * with uda_relayout_dgrad weights, their input-gradient.
+ *   y[p,co] = bias[co] + addend[p,co] + sum_{t,ci} u(p+off_t, ci) * w[co][t][ci]
+ * stats (optional, double[2][Cout], ADDED into): sum and sum of squares of y before addend. */
+typedef struct uda_conv_args {
+    uda_src_t src;
+    const float* w;        /* [Cout][ksize*ksize][round4(src.C)] */
+    int32_t Cout, ksize, dil, _pad;
+    const float* bias;     /* [Cout] or NULL */
+    const float* addend;   /* [P, ld_add] or NULL (may alias y) */
+    int64_t ld_add;
+    float* y;              /* [P, ldy] */
+    int64_t ldy;
+    double* stats;         /* [2][Cout] or NULL */
+    float* workspace;      /* needed when stats != NULL */
+    uint64_t workspace_bytes;
+} uda_conv_args_t;
+uint64_t uda_conv_workspace_bytes(int64_t P, int Cout);
+int uda_conv_fwd(const uda_conv_args_t* a, void* stream);
+
+/* weight gradient of the same convolution: dw[co][ci][kh][kw] = sum_p dy[p,co]*u(p+off_t,ci) */
+typedef struct uda_wgrad_args {
+    uda_src_t src;
+    const float* dy;       /* [P, lddy] */
+    int64_t lddy;
+    int32_t Cout, ksize, dil, _pad;
+    float* dw;             /* OIHW, contiguous */
+    float* workspace;
+    uint64_t workspace_bytes;
+} uda_wgrad_args_t;
+uint64_t uda_conv_wgrad_workspace_bytes(int64_t P, int Cout, int Cin, int ksize);
+int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream);
+
+/* ---- depthwise 3x3 (mobilenet.py:39,53): stride 1|2, dilation 1|2, "pad 0 on a padded input".
+ * border_mode 0: out-of-image taps read 0; 1: they read act(shift[c]) (quirk Q1). */
+uint64_t uda_dwconv_workspace_bytes(int64_t Pout, int C);
+int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride, int dil, int border_mode,
+                   float* y, int64_t ldy, double* stats, float* workspace, uint64_t workspace_bytes,
+                   void* stream);
+int uda_dwconv_dgrad(const float* dy, int64_t lddy, const float* w9c, int C, int stride, int dil,
+                     int N, int H, int W, float* dx, int64_t lddx, void* stream);
+int uda_dwconv_wgrad(const uda_src_t* src, const float* dy, int64_t lddy, int stride, int dil,
+                     int border_mode, float* dw /* [C][9] */, float* workspace,
+                     uint64_t workspace_bytes, void* stream);
+
+/* ---- stem conv 3x3 stride 2 pad 1, 3 -> 32, NCHW image in, NHWC out (mobilenet.py:10) */
+uint64_t uda_stem_workspace_bytes(int64_t Pout);
+int uda_stem_fwd(const float* x, int N, int H, int W, const float* w, float* y, int64_t ldy,
+                 double* stats, float* workspace, uint64_t workspace_bytes, void* stream);
+int uda_stem_wgrad(const float* x, int N, int H, int W, const float* dy, int64_t lddy, float* dw,
+                   float* workspace, uint64_t workspace_bytes, void* stream);
+
+/* ---- batch-norm pieces (F.batch_norm, training and eval) */
+int uda_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                    float* shift, float* mean, float* invstd, void* stream);
+int uda_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, int C, float eps, float* scale, float* shift,
+                       void* stream);
+/* out = transform(src) + residual */
+int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t ldr, float* out, int64_t ldo,
+                 void* stream);
+uint64_t uda_reduce_workspace_bytes(int64_t P, int C, int nq);
+/* out (double[nq][C], ADDED into): nq=1 sum, nq=2 sum and sum of squares of x */
+int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out,
+                 float* workspace, uint64_t workspace_bytes, void* stream);
+/* g = dU*mask*act'(a);  sums (double[3][C], ADDED into) = (sum g, sum g*xhat, sum dU) */
+int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
+                     const float* invstd, double* sums, float* workspace, uint64_t workspace_bytes,
+                     void* stream);
+int uda_bnbwd_finalize(const double* sums, int C, double count, int q1_border, int act,
+                       const float* shift, const float* mean, const float* invstd, float* c1,
+                       float* c2, float* dgamma, float* dbeta, void* stream);
+/* out = addend + scale*(g - c1 - xhat*c2) */
+int uda_bnbwd_apply(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
+                    const float* invstd, const float* c1, const float* c2, const float* addend,
+                    int64_t ld_add, float* out, int64_t ldo, void* stream);
+
+/* ---- resampling / pooling (F.interpolate bilinear align_corners=True, adaptive_avg_pool2d) */
+int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, float* out,
+                     int64_t ldo, int H, int W, void* stream);
+int uda_upsample_bwd(const float* dout, int64_t ldo, int N, int H, int W, int C, float* dx,
+                     int64_t ldx, int h, int w, void* stream);
+/* NHWC [N*h*w, C<=4] -> contiguous NCHW [N][C][H][W] and its adjoint */
+int uda_head_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, float* out,
+                          int H, int W, void* stream);
+int uda_head_upsample_bwd(const float* dout, int N, int C, int H, int W, float* dx, int64_t ldx,
+                          int h, int w, int accumulate, void* stream);
+/* out[n,c] = scale * sum_{p in image n} x[p,c] */
+int uda_gap_fwd(const float* x, int64_t ldx, int N, int HW, int C, float scale, float* out,
+                int64_t ldo, void* stream);
+/* out[p,c] = addend[p,c] + scale*g[n(p),c] */
+int uda_broadcast_rows(const float* g, int64_t ldg, int N, int HW, int C, float scale,
+                       const float* addend, int64_t ld_add, float* out, int64_t ldo, void* stream);
+
+/* ---- dropout keep-mask, Philox4x32-10 counter stream (nn.Dropout at aspp.py:62, decoder.py:31,36,40) */
+int uda_dropout_mask(uint8_t* mask, int64_t ldm, int64_t P, int C, float p, uint64_t seed,
+                     uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UDA_CLR_HIP_H */

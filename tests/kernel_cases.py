@@ -1,0 +1,414 @@
+"""Per-kernel parity cases: HIP kernel (through the C ABI) vs. the fp32 torch statement in
+tests/kernel_spec.py, on seeded inputs.  ``CASES`` is a list of (name, fn); fn(dev) returns the
+worst relative error (max |a-b| / max |b|) over the outputs of that case and the tolerance.
+Used by tests/test_kernels_gpu.py (asserting) and tests/gpu_report.py (printing everything)."""
+from __future__ import annotations
+
+import torch
+
+from kernel_spec import SpecKernels
+from uda_clr_amd.acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, BNRec, round4
+
+SPEC = SpecKernels()
+_HIP = None
+DETAIL = {}          # last case's per-output errors (for the report)
+
+
+def hip():
+    global _HIP
+    if _HIP is None:
+        from uda_clr_amd.kernels import HipKernels
+        _HIP = HipKernels()
+    return _HIP
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def padded(P, C, g, dev=None, scale=1.0, dtype=torch.float32):
+    """[P, C] view of a [P, round4(C)+4] buffer whose padding holds NaN (must never leak)."""
+    buf = torch.full((P, round4(C) + 4), float("nan"), dtype=dtype)
+    buf[:, :C] = torch.randn(P, C, generator=g) * scale
+    if dev is not None:
+        buf = buf.to(dev)
+    return buf[:, :C]
+
+
+def to_dev(t, dev):
+    """Move a [P, C] view keeping its row stride (so padding / alignment are preserved)."""
+    if t is None:
+        return None
+    if t.dim() == 2 and t.stride(0) != t.shape[1]:
+        base = torch.empty(t.shape[0], t.stride(0), dtype=t.dtype, device=dev)
+        if t.dtype.is_floating_point:
+            base.fill_(float("nan"))
+        v = base[:, :t.shape[1]]
+        v.copy_(t)
+        return v
+    return t.to(dev)
+
+
+def act_to(a: Act, dev) -> Act:
+    bn = None
+    if a.bn is not None:
+        bn = BNRec(a.bn.key, a.bn.mean.to(dev), a.bn.invstd.to(dev), a.bn.count, a.bn.q1_border)
+    return Act(to_dev(a.x, dev), a.N, a.H, a.W, None if a.scale is None else a.scale.to(dev),
+               None if a.shift is None else a.shift.to(dev), a.act, to_dev(a.mask, dev), a.mask_scale, bn)
+
+
+def make_src(N, H, W, C, g, lazy=True, act=ACT_RELU, mask=False, bn=False, q1=False):
+    P = N * H * W
+    x = padded(P, C, g)
+    scale = shift = None
+    if lazy:
+        scale = 0.5 + torch.rand(C, generator=g)
+        shift = 0.3 * torch.randn(C, generator=g)
+    m, ms = None, 1.0
+    if mask:
+        mb = torch.zeros(P, round4(C), dtype=torch.uint8)
+        mb[:, :C] = (torch.rand(P, C, generator=g) > 0.3).to(torch.uint8)
+        m, ms = mb[:, :C], 1.0 / 0.7
+    rec = None
+    if bn:
+        rec = BNRec("t", 0.2 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g), float(P * (1.3 if q1 else 1.0)), q1)
+    return Act(x, N, H, W, scale, shift, act if lazy else ACT_NONE, m, ms, rec)
+
+
+# ------------------------------------------------------------------------------------- cases
+def case_conv(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, bias=False, addend=False, stats=True, seed=0):
+    def run(dev):
+        g = gen(seed)
+        src = make_src(N, H, W, Cin, g, lazy, ACT_RELU6 if Cin % 8 else ACT_RELU, mask)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g) if bias else None
+        P = N * H * W
+        ad = padded(P, Cout, g) if addend else None
+        out_r = padded(P, Cout, g)
+        st_r = torch.zeros(2, Cout, dtype=torch.float64) if stats else None
+        SPEC.conv(src, SPEC.relayout_ohwi(w), k, dil, out_r, b, ad, st_r)
+        K = hip()
+        out_h = to_dev(padded(P, Cout, g), dev)
+        st_h = torch.zeros(2, Cout, dtype=torch.float64, device=dev) if stats else None
+        wl = K.relayout_ohwi(w.to(dev))
+        errs = [rel(wl, SPEC.relayout_ohwi(w))]
+        K.conv(act_to(src, dev), wl, k, dil, out_h, None if b is None else b.to(dev), to_dev(ad, dev), st_h)
+        errs.append(rel(out_h, out_r))
+        if stats:
+            errs.append(rel(st_h, st_r))
+        return max(errs), 2e-5
+    return run
+
+
+def case_dgrad(N, H, W, Cin, Cout, k, dil, accumulate=False, seed=1):
+    """input-gradient of a conv = conv of dy with the dgrad weight layout"""
+    def run(dev):
+        g = gen(seed)
+        P = N * H * W
+        dy = padded(P, Cout, g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        ad = padded(P, Cin, g) if accumulate else None
+        ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy.reshape(N, H, W, Cout).permute(0, 3, 1, 2), 1,
+                                         dil * (k // 2), dil).permute(0, 2, 3, 1).reshape(P, Cin)
+        if ad is not None:
+            ref = ref + ad
+        K = hip()
+        wd = K.relayout_dgrad(w.to(dev))
+        e0 = rel(wd, SPEC.relayout_dgrad(w))
+        out = to_dev(padded(P, Cin, g), dev)
+        adh = to_dev(ad, dev)
+        if accumulate:      # in-place accumulate, as the engine uses it
+            out.copy_(adh)
+            adh = out
+        K.conv(Act(to_dev(dy, dev), N, H, W), wd, k, dil, out, addend=adh)
+        return max(e0, rel(out, ref)), 2e-5
+    return run
+
+
+def case_wgrad(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, seed=2):
+    def run(dev):
+        g = gen(seed)
+        src = make_src(N, H, W, Cin, g, lazy, ACT_RELU, mask)
+        dy = padded(N * H * W, Cout, g)
+        ref = torch.empty(Cout, Cin, k, k)
+        SPEC.conv_wgrad(src, dy, k, dil, ref)
+        out = torch.empty(Cout, Cin, k, k, device=dev)
+        hip().conv_wgrad(act_to(src, dev), to_dev(dy, dev), k, dil, out)
+        return rel(out, ref), 3e-5
+    return run
+
+
+def case_dw(N, H, W, C, stride, dil, border, seed=3):
+    def run(dev):
+        g = gen(seed)
+        src = make_src(N, H, W, C, g, True, ACT_RELU6)
+        w = torch.randn(C, 1, 3, 3, generator=g) / 3.0
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        Po = N * Ho * Wo
+        K = hip()
+        w9 = SPEC.relayout_dw(w)
+        w9h = K.relayout_dw(w.to(dev))
+        errs = [rel(w9h, w9)]
+        y_r, st_r = padded(Po, C, g), torch.zeros(2, C, dtype=torch.float64)
+        SPEC.dwconv_fwd(src, w9, stride, dil, border, y_r, st_r)
+        y_h, st_h = to_dev(padded(Po, C, g), dev), torch.zeros(2, C, dtype=torch.float64, device=dev)
+        sh = act_to(src, dev)
+        K.dwconv_fwd(sh, w9h, stride, dil, border, y_h, st_h)
+        errs += [rel(y_h, y_r), rel(st_h, st_r)]
+        dy = padded(Po, C, g)
+        dx_r = padded(N * H * W, C, g)
+        SPEC.dwconv_dgrad(dy, w9, stride, dil, N, H, W, dx_r)
+        dx_h = to_dev(padded(N * H * W, C, g), dev)
+        K.dwconv_dgrad(to_dev(dy, dev), w9h, stride, dil, N, H, W, dx_h)
+        errs.append(rel(dx_h, dx_r))
+        dw_r = torch.empty(C, 1, 3, 3)
+        SPEC.dwconv_wgrad(src, dy, stride, dil, border, dw_r)
+        dw_h = torch.empty(C, 1, 3, 3, device=dev)
+        K.dwconv_wgrad(sh, to_dev(dy, dev), stride, dil, border, dw_h)
+        errs.append(rel(dw_h, dw_r))
+        return max(errs), 3e-5
+    return run
+
+
+def case_stem(N, H, W, seed=4):
+    def run(dev):
+        g = gen(seed)
+        x = torch.randn(N, 3, H, W, generator=g)
+        w = torch.randn(32, 3, 3, 3, generator=g) / 5.0
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        y_r, st_r = padded(Po, 32, g), torch.zeros(2, 32, dtype=torch.float64)
+        SPEC.stem_fwd(x, w, y_r, st_r)
+        K = hip()
+        y_h, st_h = to_dev(padded(Po, 32, g), dev), torch.zeros(2, 32, dtype=torch.float64, device=dev)
+        K.stem_fwd(x.to(dev), w.to(dev), y_h, st_h)
+        dy = padded(Po, 32, g)
+        dw_r, dw_h = torch.empty(32, 3, 3, 3), torch.empty(32, 3, 3, 3, device=dev)
+        SPEC.stem_wgrad(x, dy, dw_r)
+        K.stem_wgrad(x.to(dev), to_dev(dy, dev), dw_h)
+        return max(rel(y_h, y_r), rel(st_h, st_r), rel(dw_h, dw_r)), 3e-5
+    return run
+
+
+def case_bn(P, C, q1=False, mask=False, training=True, seed=5):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        errs = []
+        x = padded(P, C, g, scale=2.0)
+        st_r = torch.zeros(2, C, dtype=torch.float64)
+        SPEC.colstats(x, st_r)
+        st_h = torch.zeros(2, C, dtype=torch.float64, device=dev)
+        K.colstats(to_dev(x, dev), st_h)
+        errs.append(rel(st_h, st_r))
+        gamma, beta = 0.5 + torch.rand(C, generator=g), torch.randn(C, generator=g)
+        rm, rv = torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+        cr = torch.empty(4, C)
+        ch = torch.empty(4, C, device=dev)
+        rmh, rvh = rm.to(dev), rv.to(dev)
+        cnt = float(P * (1.25 if q1 else 1.0))
+        if training:
+            SPEC.bn_finalize(st_r, cnt, gamma, beta, rm, rv, 0.1, 1e-5, cr[0], cr[1], cr[2], cr[3])
+            K.bn_finalize(st_h, cnt, gamma.to(dev), beta.to(dev), rmh, rvh, 0.1, 1e-5, ch[0], ch[1], ch[2], ch[3])
+            errs += [rel(ch, cr), rel(rmh, rm), rel(rvh, rv)]
+        else:
+            SPEC.bn_eval_coeffs(gamma, beta, rm, rv, 1e-5, cr[0], cr[1])
+            K.bn_eval_coeffs(gamma.to(dev), beta.to(dev), rmh, rvh, 1e-5, ch[0], ch[1])
+            cr[2:], ch[2:] = 0.0, 0.0
+            errs.append(rel(ch[:2], cr[:2]))
+        if C % 4 == 0:
+            m = None
+            if mask:
+                m = (torch.rand(P, C, generator=g) > 0.5).to(torch.uint8)
+            src = Act(x, 1, 1, P, cr[0].clone(), cr[1].clone(), ACT_RELU, m, 2.0 if mask else 1.0)
+            res = padded(P, C, g)
+            o_r = padded(P, C, g)
+            SPEC.bn_apply(src, o_r, res)
+            o_h = to_dev(padded(P, C, g), dev)
+            K.bn_apply(act_to(src, dev), o_h, to_dev(res, dev))
+            errs.append(rel(o_h, o_r))
+        if training:
+            mb = None
+            if mask:
+                mbuf = torch.zeros(P, round4(C), dtype=torch.uint8)
+                mbuf[:, :C] = (torch.rand(P, C, generator=g) > 0.5).to(torch.uint8)
+                mb = mbuf[:, :C]
+            y = Act(x, 1, 1, P, cr[0].clone(), cr[1].clone(), ACT_RELU6 if q1 else ACT_RELU, mb, 2.0 if mask else 1.0,
+                    BNRec("t", cr[2].clone(), cr[3].clone(), cnt, q1))
+            dU = padded(P, C, g)
+            s_r = torch.zeros(3, C, dtype=torch.float64)
+            SPEC.bnbwd_reduce(dU, y, s_r)
+            yh = act_to(y, dev)
+            dUh = to_dev(dU, dev)
+            s_h = torch.zeros(3, C, dtype=torch.float64, device=dev)
+            K.bnbwd_reduce(dUh, yh, s_h)
+            errs.append(rel(s_h, s_r))
+            gr, gh = torch.empty(4, C), torch.empty(4, C, device=dev)
+            SPEC.bnbwd_finalize(s_r, y, gr[0], gr[1], gr[2], gr[3])
+            K.bnbwd_finalize(s_h, yh, gh[0], gh[1], gh[2], gh[3])
+            errs.append(rel(gh, gr))
+            ad = padded(P, C, g)
+            o_r = padded(P, C, g)
+            SPEC.bnbwd_apply(dU, y, gr[0], gr[1], o_r, ad)
+            adh = to_dev(ad, dev)
+            K.bnbwd_apply(dUh, yh, gh[0], gh[1], adh, adh)      # in place over the addend
+            errs.append(rel(adh, o_r))
+        DETAIL.clear()
+        DETAIL.update({"errs": ["%.1e" % e for e in errs]})
+        return max(errs), 3e-5
+    return run
+
+
+def case_resample(N, h, w, H, W, C, seed=6):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        x = padded(N * h * w, C, g)
+        o_r, o_h = padded(N * H * W, C, g), to_dev(padded(N * H * W, C, g), dev)
+        SPEC.upsample_fwd(x, N, h, w, o_r, H, W)
+        K.upsample_fwd(to_dev(x, dev), N, h, w, o_h, H, W)
+        ref_t = torch.nn.functional.interpolate(x.reshape(N, h, w, C).permute(0, 3, 1, 2), size=(H, W), mode="bilinear",
+                                                align_corners=True).permute(0, 2, 3, 1).reshape(N * H * W, C)
+        errs = [rel(o_h, o_r), rel(o_h, ref_t)]
+        d = padded(N * H * W, C, g)
+        dx_r, dx_h = padded(N * h * w, C, g), to_dev(padded(N * h * w, C, g), dev)
+        SPEC.upsample_bwd(d, N, H, W, dx_r, h, w)
+        K.upsample_bwd(to_dev(d, dev), N, H, W, dx_h, h, w)
+        errs.append(rel(dx_h, dx_r))
+        return max(errs), 2e-5
+    return run
+
+
+def case_head(N, h, w, H, W, C, seed=7):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        x = padded(N * h * w, C, g)
+        o_r, o_h = torch.empty(N, C, H, W), torch.empty(N, C, H, W, device=dev)
+        SPEC.head_upsample_fwd(x, N, h, w, o_r)
+        K.head_upsample_fwd(to_dev(x, dev), N, h, w, o_h)
+        ref_t = torch.nn.functional.interpolate(x.reshape(N, h, w, C).permute(0, 3, 1, 2), size=(H, W), mode="bilinear",
+                                                align_corners=True)
+        errs = [rel(o_h, o_r), rel(o_h, ref_t)]
+        d = torch.randn(N, C, H, W, generator=g)
+        base = padded(N * h * w, C, g)
+        dx_r = base.clone()
+        SPEC.head_upsample_bwd(d, dx_r, N, h, w, True)
+        dx_h = to_dev(base, dev)
+        K.head_upsample_bwd(d.to(dev), dx_h, N, h, w, True)
+        errs.append(rel(dx_h, dx_r))
+        dx_h2 = to_dev(base, dev)
+        K.head_upsample_bwd(d.to(dev), dx_h2, N, h, w, False)
+        errs.append(rel(dx_h2, dx_r - base))
+        return max(errs), 2e-5
+    return run
+
+
+def case_gap(N, HW, C, seed=8):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        x = padded(N * HW, C, g)
+        o_r, o_h = torch.empty(N, C), torch.empty(N, C, device=dev)
+        SPEC.gap_fwd(x, N, o_r, 1.0 / HW)
+        K.gap_fwd(to_dev(x, dev), N, o_h, 1.0 / HW)
+        errs = [rel(o_h, o_r)]
+        ad = padded(N * HW, C, g)
+        b_r, b_h = padded(N * HW, C, g), to_dev(padded(N * HW, C, g), dev)
+        SPEC.broadcast_rows(o_r, N, b_r, 0.25, ad)
+        K.broadcast_rows(o_r.to(dev), N, b_h, 0.25, to_dev(ad, dev))
+        errs.append(rel(b_h, b_r))
+        return max(errs), 2e-5
+    return run
+
+
+def case_dropout(P, C, p, seed=9):
+    def run(dev):
+        K = hip()
+        m = torch.zeros(P, round4(C), dtype=torch.uint8, device=dev)[:, :C]
+        K.dropout_mask(m, p, 1234, 7)
+        m2 = torch.zeros(P, round4(C), dtype=torch.uint8, device=dev)[:, :C]
+        K.dropout_mask(m2, p, 1234, 7)
+        m3 = torch.zeros(P, round4(C), dtype=torch.uint8, device=dev)[:, :C]
+        K.dropout_mask(m3, p, 1234, 8)
+        assert torch.equal(m, m2), "same (seed, offset) must reproduce the mask"
+        assert not torch.equal(m, m3), "different offsets must give different masks"
+        assert int(m.max()) <= 1
+        keep = m.float().mean().item()
+        col = m.float().mean(0)
+        # binomial tolerance (5 sigma) on the overall rate, loose bound per column
+        sig = ((1 - p) * p / (P * C)) ** 0.5
+        err = abs(keep - (1 - p)) / (5 * sig)
+        assert (col - (1 - p)).abs().max().item() < 8 * ((1 - p) * p / P) ** 0.5
+        return err, 1.0
+    return run
+
+
+CASES = [
+    # 1x1 convs of the backbone (narrow N configs, small K, Q1-style sizes)
+    ("conv1x1 16->96 relu6", case_conv(2, 24, 20, 16, 96, 1, 1)),
+    ("conv1x1 96->24 none-lazy", case_conv(2, 17, 13, 96, 24, 1, 1, lazy=False)),
+    ("conv1x1 144->32", case_conv(1, 16, 16, 144, 32, 1, 1)),
+    ("conv1x1 32->192 (128-wide tiles)", case_conv(2, 12, 12, 32, 192, 1, 1)),
+    ("conv1x1 960->320", case_conv(2, 8, 8, 960, 320, 1, 1, stats=True)),
+    ("conv1x1 1280->256 relu", case_conv(2, 8, 8, 1280, 256, 1, 1)),
+    ("conv1x1 305->2 bias mask (C%4!=0)", case_conv(2, 16, 16, 305, 2, 1, 1, mask=True, bias=True, stats=False)),
+    ("conv1x1 256->1 bias mask", case_conv(2, 16, 16, 256, 1, 1, 1, mask=True, bias=True, stats=False)),
+    ("conv1x1 320->256 P=N (gap branch)", case_conv(4, 1, 1, 320, 256, 1, 1, lazy=False)),
+    ("conv1x1 24->48 addend", case_conv(2, 16, 16, 24, 48, 1, 1, addend=True, stats=False)),
+    # 3x3 convs
+    ("conv3x3 304->256 p1 mask", case_conv(2, 16, 16, 304, 256, 3, 1, lazy=False)),
+    ("conv3x3 256->256 relu mask", case_conv(2, 16, 12, 256, 256, 3, 1, mask=True)),
+    ("conv3x3 320->256 dil6", case_conv(2, 8, 8, 320, 256, 3, 6, lazy=False)),
+    ("conv3x3 320->256 dil12 (mostly padding)", case_conv(2, 8, 8, 320, 256, 3, 12, lazy=False)),
+    ("conv3x3 64->40 dil2 odd sizes", case_conv(1, 11, 9, 64, 40, 3, 2)),
+    # dgrad through the same kernel
+    ("dgrad1x1 96<-16", case_dgrad(2, 12, 12, 96, 16, 1, 1)),
+    ("dgrad1x1 305<-2", case_dgrad(2, 16, 16, 305, 2, 1, 1)),
+    ("dgrad1x1 256<-1", case_dgrad(2, 16, 16, 256, 1, 1, 1)),
+    ("dgrad3x3 304<-256 accumulate", case_dgrad(2, 12, 12, 304, 256, 3, 1, accumulate=True)),
+    ("dgrad3x3 320<-256 dil6 accumulate", case_dgrad(2, 8, 8, 320, 256, 3, 6, accumulate=True)),
+    # wgrad
+    ("wgrad1x1 16->96", case_wgrad(2, 24, 20, 16, 96, 1, 1)),
+    ("wgrad1x1 96->24", case_wgrad(2, 17, 13, 96, 24, 1, 1)),
+    ("wgrad1x1 32->16 (64x64 tiles)", case_wgrad(2, 16, 16, 32, 16, 1, 1)),
+    ("wgrad1x1 960->320", case_wgrad(2, 8, 8, 960, 320, 1, 1)),
+    ("wgrad1x1 305->2 mask", case_wgrad(2, 16, 16, 305, 2, 1, 1, mask=True)),
+    ("wgrad1x1 256->1 mask", case_wgrad(2, 16, 16, 256, 1, 1, 1, mask=True)),
+    ("wgrad1x1 320->256 P=4", case_wgrad(4, 1, 1, 320, 256, 1, 1, lazy=False)),
+    ("wgrad3x3 304->256", case_wgrad(2, 16, 16, 304, 256, 3, 1, lazy=False)),
+    ("wgrad3x3 256->256 mask", case_wgrad(2, 16, 12, 256, 256, 3, 1, mask=True)),
+    ("wgrad3x3 320->256 dil6", case_wgrad(2, 8, 8, 320, 256, 3, 6, lazy=False)),
+    ("wgrad3x3 64->40 dil2", case_wgrad(1, 11, 9, 64, 40, 3, 2)),
+    # depthwise
+    ("dw 32 s1 d1 border0", case_dw(2, 16, 16, 32, 1, 1, 0)),
+    ("dw 96 s2 d1 border1", case_dw(2, 16, 16, 96, 2, 1, 1)),
+    ("dw 144 s1 d1 border1 odd", case_dw(1, 13, 11, 144, 1, 1, 1)),
+    ("dw 960 s1 d2 border1", case_dw(2, 8, 8, 960, 1, 2, 1)),
+    ("dw 576 s1 d1 border1", case_dw(2, 8, 8, 576, 1, 1, 1)),
+    ("stem 2x3x32x32", case_stem(2, 32, 32)),
+    ("stem 1x3x48x80", case_stem(1, 48, 80)),
+    # batch norm pieces
+    ("bn C=32 P=3000", case_bn(3000, 32)),
+    ("bn C=96 q1", case_bn(1500, 96, q1=True)),
+    ("bn C=256 mask", case_bn(700, 256, mask=True)),
+    ("bn C=305 mask (C%4!=0)", case_bn(600, 305, mask=True)),
+    ("bn C=1024 (concat)", case_bn(300, 1024)),
+    ("bn eval C=144", case_bn(500, 144, training=False)),
+    ("bn C=256 P=4", case_bn(4, 256)),
+    # resampling
+    ("upsample 4x4->16x16 C=256", case_resample(2, 4, 4, 16, 16, 256)),
+    ("upsample 8x6->32x24 C=64", case_resample(1, 8, 6, 32, 24, 64)),
+    ("head 16x16->64x64 C=2", case_head(2, 16, 16, 64, 64, 2)),
+    ("head 12x10->48x40 C=1", case_head(1, 12, 10, 48, 40, 1)),
+    ("gap C=320", case_gap(3, 64, 320)),
+    ("gap C=256 HW=16", case_gap(4, 16, 256)),
+    ("dropout p=.5", case_dropout(4096, 256, 0.5)),
+    ("dropout p=.1 C=305", case_dropout(4096, 305, 0.1)),
+]

@@ -1,0 +1,138 @@
+"""Whole-generator parity helpers shared by the GPU tests, the GPU report and smoke()."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from oracle import deeplab_ref, step_ref
+from uda_clr_amd.networks.deeplabv3 import DeepLab
+
+NAMES = ("x1", "x2", "feature", "x_bu_feature", "x_feature", "x1_before", "x2_before")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def seeded_model(seed=1337, perturb=False):
+    torch.manual_seed(seed)
+    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True, freeze_bn=False,
+                method="prototype_full")
+    if perturb:
+        g = torch.Generator().manual_seed(5)
+        for k, v in m.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.data.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+                mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    return m
+
+
+def eval_parity(dev, B=2, S=64, perturb=True):
+    """HIP eval forward vs the oracle on the same weights; returns {output: rel err}."""
+    m = seeded_model(perturb=perturb).eval()
+    sd = deeplab_ref.canonical_state(m.state_dict())
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        ref = deeplab_ref.deeplab_forward(sd, x, training=False)
+        m.to(dev)
+        out = m(x.to(dev))
+    return {n: rel(a, b) for n, a, b in zip(NAMES, out, ref)}
+
+
+def train_parity(dev, B=2, S=64, extra_heads=True):
+    """HIP training forward + backward (injected dropout masks) vs the fp64 oracle.  Returns
+    (forward errs vs fp32 oracle, {param: (err vs fp64, fp32-oracle err vs fp64)}, running-stat err)."""
+    m = seeded_model(perturb=True).train()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    tmap = (torch.rand(B, 2, S, S, generator=gen) > 0.5).float()
+    tbd = torch.rand(B, 1, S, S, generator=gen)
+    masks = deeplab_ref.draw_masks(B, S, S, gen)
+    wf = [torch.randn(t, generator=gen) for t in (256, 304, 305, 2, 1)]
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def total(outs, dt, dv):
+        loss = step_ref.seg_loss(outs[0], outs[1], tmap.to(dv, dt), tbd.to(dv, dt))
+        if extra_heads:
+            for t, w in zip(outs[2:], wf):
+                loss = loss + 1e-2 * (t * w.to(dv, dt).view(1, -1, 1, 1)).pow(2).mean()
+        return loss
+
+    o32 = deeplab_ref.canonical_state(sd0, requires_grad=True)
+    r32 = deeplab_ref.deeplab_forward(o32, x, training=True, masks=masks)
+    total(r32, torch.float32, "cpu").backward()
+    o64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.clone())
+           for k, v in deeplab_ref.canonical_state(sd0, requires_grad=True).items()}
+    r64 = deeplab_ref.deeplab_forward(o64, x.double(), training=True, masks=masks)
+    total(r64, torch.float64, "cpu").backward()
+    m.to(dev)
+    m.set_dropout_masks(masks)
+    out = m(x.to(dev))
+    total(out, torch.float32, dev).backward()
+    fwd = {n: rel(a, b) for n, a, b in zip(NAMES, out, r32)}
+    live = m._flat_state()
+    grads = {}
+    for k in deeplab_ref.parameter_keys(o32):
+        g = live[k].grad
+        grads[k] = (float("inf") if g is None else rel(g, o64[k].grad), rel(o32[k].grad, o64[k].grad))
+    stats = max(rel(live[k], v) for k, v in o32.items() if k.endswith("running_mean") or k.endswith("running_var"))
+    return fwd, grads, stats
+
+
+def golden_parity(dev, tag):
+    """HIP path vs the fixtures written by the reference itself (tests/golden/forward_<tag>.npz):
+    seeded init, seeded input, eval outputs (checksums + samples), train loss and grad norms with the
+    oracle-recovered dropout masks of the reference's own draw."""
+    z = np.load(os.path.join(GOLDEN, "forward_%s.npz" % tag))
+    B, S = int(z["B"]), int(z["S"])
+    m = seeded_model()
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    errs = {}
+    m.to(dev).eval()
+    with torch.no_grad():
+        out = m(x.to(dev))
+    for n, t in zip(NAMES, out):
+        d = t.double().cpu()
+        f = d.reshape(-1)
+        idx = torch.linspace(0, f.numel() - 1, 97).long()
+        errs["eval." + n + ".smp"] = (f[idx] - torch.from_numpy(z["eval.%s.smp" % n])).abs().max().item() / max(
+            float(np.abs(z["eval.%s.smp" % n]).max()), 1e-30)
+        errs["eval." + n + ".abs"] = abs(d.abs().sum().item() - float(z["eval.%s.abs" % n])) / float(z["eval.%s.abs" % n])
+    # training step: the reference drew its dropout masks from torch.manual_seed(dropout_seed); the
+    # oracle (pinned bit-exact to the reference) re-draws the same stream and hands the masks over
+    from make_golden_inputs import synth_targets
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    m.train()
+    sd0 = deeplab_ref.canonical_state({k: v.cpu() for k, v in m.state_dict().items()})
+    rec = {}
+    torch.manual_seed(int(z["dropout_seed"]))
+    with torch.no_grad():
+        deeplab_ref.deeplab_forward(sd0, x, training=True, record=rec)
+    for k, v in rec.items():
+        assert int(v.sum()) == int(z["mask.%s.sum" % k]), "dropout stream differs from the reference's draw"
+    m.set_dropout_masks(rec)
+    out = m(x.to(dev))
+    loss = step_ref.seg_loss(out[0], out[1], tmap.to(dev), tbd.to(dev))
+    loss.backward()
+    errs["train.loss"] = abs(loss.item() - float(z["train.loss"])) / abs(float(z["train.loss"]))
+    for n, t in zip(NAMES, out):
+        d = t.detach().double().cpu()
+        errs["train." + n + ".abs"] = abs(d.abs().sum().item() - float(z["train.%s.abs" % n])) / float(z["train.%s.abs" % n])
+    live = m._flat_state()
+    gn = np.array([live[k].grad.double().norm().item() for k in z["train.grad_keys"]])
+    errs["train.grad_norm"] = float(np.max(np.abs(gn - z["train.grad_norm"]) / np.maximum(z["train.grad_norm"], 1e-12)))
+    bs = np.array([live[k].double().sum().item() for k in z["train.bn_keys"]])
+    errs["train.bn_sum"] = float(np.max(np.abs(bs - z["train.bn_sum"]) / np.maximum(np.abs(z["train.bn_sum"]), 1e-3)))
+    return errs

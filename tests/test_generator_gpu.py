@@ -1,0 +1,49 @@
+"""-m gpu: the whole generator (one autograd node on the HIP kernels) against the oracle and
+against the fixtures the reference itself produced."""
+import pytest
+import torch
+
+import model_cases
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("size", [64, 96])
+def test_eval_forward_matches_oracle(size):
+    errs = model_cases.eval_parity(DEV, 2, size)
+    assert max(errs.values()) < 1e-3, errs          # north_star tolerance: 1e-3 relative fp32
+
+
+def test_train_forward_backward_matches_oracle():
+    fwd, grads, stats = model_cases.train_parity(DEV)
+    assert max(fwd.values()) < 1e-3, fwd
+    assert stats < 1e-3
+    # gradients: no further from the fp64 oracle than 3x the fp32 oracle's own distance to it
+    bad = {k: v for k, v in grads.items() if not (v[0] < 3 * v[1] + 1e-4)}
+    assert not bad, list(bad.items())[:10]
+
+
+@pytest.mark.parametrize("tag", ["64", "512"])
+def test_matches_reference_fixtures(tag):
+    errs = model_cases.golden_parity(DEV, tag)
+    tol = {"train.grad_norm": 2e-2, "train.bn_sum": 1e-3}
+    for k, v in errs.items():
+        assert v < tol.get(k, 1e-3), (k, v)
+
+
+def test_no_grad_and_determinism():
+    m = model_cases.seeded_model().to(DEV).train()
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    from oracle import deeplab_ref
+    masks = deeplab_ref.draw_masks(2, 64, 64, torch.Generator().manual_seed(2))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    outs = []
+    for _ in range(2):
+        m.load_state_dict(sd)
+        m.set_dropout_masks(masks)
+        with torch.no_grad():
+            outs.append([t.clone() for t in m(x)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), "the forward path must be bitwise reproducible"
+    assert not outs[0][0].requires_grad

@@ -1,0 +1,430 @@
+// Depthwise 3x3 convolution (MobileNetV2 inverted residual, mobilenet.py:39,53) and the 3->32
+// stem convolution (mobilenet.py:10) for gfx950.  All of these are HBM-bound (1.7 / 9.8 FLOP per
+// byte): the design goal is one coalesced 16-byte access per lane per tap, the BN
+// affine + ReLU6 of the PRODUCER applied on load, and the BN statistics of THIS conv accumulated
+// in the epilogue so the activation is written once and never re-read for normalisation.
+//
+// Thread mapping (shared by the depthwise kernels): channel group cg = tid % G (G = C/4 float4
+// groups), pixel lane pl = tid / G; a workgroup walks ITER strips of PP = 256/G consecutive
+// output pixels, so the 64 lanes of a wave read G*16 contiguous bytes per pixel.
+#include "common.h"
+
+int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hipStream_t st);
+
+#define DW_ITER_FWD 8
+#define DW_ITER_RED 32
+
+struct DwArgs {
+    uda_src_t src;
+    const float* w9c;       // [9][C]
+    int stride, dil, border_mode;
+    int Ho, Wo;
+    float* y;               // fwd: output; wgrad: unused
+    int64_t ldy;
+    const float* dy;        // wgrad: gradient of the output
+    int64_t lddy;
+    float* part;            // fwd: [nWG][2][C]; wgrad: [nWG][9][C]
+};
+
+__device__ __forceinline__ float4 dw_transform(float4 v, const Xf4& xf, bool has_xf, int act) {
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u = r[j];
+        if (has_xf) u = u * xf.sc[j] + xf.sh[j];
+        r[j] = uda_act(u, act);
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwArgs a) {
+    __shared__ float red[2 * 1024];
+    const int C = a.src.C, G = C >> 2, PP = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
+    const bool active = pl < PP;
+    const int H = a.src.H, W = a.src.W;
+    const int64_t Pout = (int64_t)a.src.N * a.Ho * a.Wo;
+    const int c0 = cg * 4;
+    const bool has_xf = a.src.scale != nullptr;
+    const int act = a.src.act;
+    Xf4 xf;
+    uda_load_xf4(xf, a.src.scale, a.src.shift, c0, C);
+    float4 bval = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.border_mode == 1)
+        bval = make_float4(uda_act(xf.sh[0], act), uda_act(xf.sh[1], act), uda_act(xf.sh[2], act), uda_act(xf.sh[3], act));
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = active ? uda_ld4(a.w9c + t * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const int64_t base = (int64_t)blockIdx.x * (PP * DW_ITER_FWD);
+    for (int it = 0; it < DW_ITER_FWD; ++it) {
+        const int64_t po = base + (int64_t)it * PP + pl;
+        if (!active || po >= Pout) continue;
+        const int ow = (int)(po % a.Wo), oh = (int)((po / a.Wo) % a.Ho), n = (int)(po / ((int64_t)a.Wo * a.Ho));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * a.stride + (kh - 1) * a.dil;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * a.stride + (kw - 1) * a.dil;
+                float4 u = bval;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    u = dw_transform(uda_ld4(a.src.x + (((int64_t)n * H + ih) * W + iw) * a.src.ldx + c0), xf, has_xf, act);
+                const float4 ww = w[kh * 3 + kw];
+                acc.x += ww.x * u.x; acc.y += ww.y * u.y; acc.z += ww.z * u.z; acc.w += ww.w * u.w;
+            }
+        }
+        uda_st4(a.y + po * a.ldy + c0, acc);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+    }
+    if (a.part == nullptr) return;
+    if (active) {
+        uda_st4(&red[(pl * 2 + 0) * C + c0], s1);
+        uda_st4(&red[(pl * 2 + 1) * C + c0], s2);
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * C; e += 256) {
+        float t = 0.f;
+        for (int p = 0; p < PP; ++p) t += red[p * 2 * C + e];
+        a.part[(int64_t)blockIdx.x * 2 * C + e] = t;
+    }
+}
+
+// gradient w.r.t. the interior H x W positions of the (padded) depthwise input
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ w9c, int C, int stride,
+                                                            int dil, int N, int H, int W, int Ho, int Wo,
+                                                            float* __restrict__ dx, int64_t lddx) {
+    const int G = C >> 2;
+    const int64_t total = (int64_t)N * H * W * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int64_t p = e / G;
+        const int iw = (int)(p % W), ih = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        const int c0 = cg * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int nh = ih - (kh - 1) * dil;
+            if (nh < 0 || nh % stride) continue;
+            const int oh = nh / stride;
+            if (oh >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int nw = iw - (kw - 1) * dil;
+                if (nw < 0 || nw % stride) continue;
+                const int ow = nw / stride;
+                if (ow >= Wo) continue;
+                const float4 g = uda_ld4(dy + (((int64_t)n * Ho + oh) * Wo + ow) * lddy + c0);
+                const float4 ww = uda_ld4(w9c + (kh * 3 + kw) * C + c0);
+                acc.x += ww.x * g.x; acc.y += ww.y * g.y; acc.z += ww.z * g.z; acc.w += ww.w * g.w;
+            }
+        }
+        uda_st4(dx + p * lddx + c0, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwArgs a) {
+    __shared__ float red[9 * 1024];
+    const int C = a.src.C, G = C >> 2, PP = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
+    const bool active = pl < PP;
+    const int H = a.src.H, W = a.src.W;
+    const int64_t Pout = (int64_t)a.src.N * a.Ho * a.Wo;
+    const int c0 = cg * 4;
+    const bool has_xf = a.src.scale != nullptr;
+    const int act = a.src.act;
+    Xf4 xf;
+    uda_load_xf4(xf, a.src.scale, a.src.shift, c0, C);
+    float4 bval = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.border_mode == 1)
+        bval = make_float4(uda_act(xf.sh[0], act), uda_act(xf.sh[1], act), uda_act(xf.sh[2], act), uda_act(xf.sh[3], act));
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t base = (int64_t)blockIdx.x * (PP * DW_ITER_RED);
+    for (int it = 0; it < DW_ITER_RED; ++it) {
+        const int64_t po = base + (int64_t)it * PP + pl;
+        if (!active || po >= Pout) continue;
+        const int ow = (int)(po % a.Wo), oh = (int)((po / a.Wo) % a.Ho), n = (int)(po / ((int64_t)a.Wo * a.Ho));
+        const float4 g = uda_ld4(a.dy + po * a.lddy + c0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * a.stride + (kh - 1) * a.dil;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * a.stride + (kw - 1) * a.dil;
+                float4 u = bval;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    u = dw_transform(uda_ld4(a.src.x + (((int64_t)n * H + ih) * W + iw) * a.src.ldx + c0), xf, has_xf, act);
+                float4& s = acc[kh * 3 + kw];
+                s.x += g.x * u.x; s.y += g.y * u.y; s.z += g.z * u.z; s.w += g.w * u.w;
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) uda_st4(&red[(pl * 9 + t) * C + c0], acc[t]);
+    }
+    __syncthreads();
+    for (int e = tid; e < 9 * C; e += 256) {
+        float t = 0.f;
+        for (int p = 0; p < PP; ++p) t += red[p * 9 * C + e];
+        a.part[(int64_t)blockIdx.x * 9 * C + e] = t;
+    }
+}
+
+// dw[c][t] (float) = sums[t][c] (double)
+__global__ void dw_wgrad_store_kernel(const double* __restrict__ sums, int C, float* __restrict__ dw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 9 * C) dw[(e % C) * 9 + e / C] = (float)sums[e];
+}
+
+static int dw_check(const uda_src_t* s, const char* who) {
+    UDA_REQUIRE(s && s->x && uda_aligned16(s->x) && s->ldx % 4 == 0 && s->ldx >= s->C, "%s: bad src", who);
+    UDA_REQUIRE(s->C % 4 == 0 && s->C >= 4 && s->C <= 1024, "%s: C=%d must be a multiple of 4 in [4,1024]", who, s->C);
+    UDA_REQUIRE((s->scale == nullptr) == (s->shift == nullptr), "%s: scale/shift must come together", who);
+    UDA_REQUIRE(s->mask == nullptr, "%s: dropout masks are not supported on depthwise inputs", who);
+    return 0;
+}
+
+static inline int dw_pixels_per_wg(int C, int iter) { return (256 / (C / 4)) * iter; }
+
+extern "C" uint64_t uda_dwconv_workspace_bytes(int64_t Pout, int C) {
+    if (C < 4) return 0;
+    const uint64_t fwd = (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_FWD)) * 2 * C * sizeof(float);
+    const uint64_t wg = (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED)) * 9 * C * sizeof(float) + 9 * C * sizeof(double);
+    return fwd > wg ? fwd : wg;
+}
+
+extern "C" int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride, int dil, int border_mode,
+                              float* y, int64_t ldy, double* stats, float* workspace, uint64_t workspace_bytes,
+                              void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = dw_check(src, "uda_dwconv_fwd")) return e;
+    UDA_REQUIRE(w9c && uda_aligned16(w9c) && y && uda_aligned16(y) && ldy % 4 == 0 && ldy >= src->C, "uda_dwconv_fwd: bad pointers");
+    UDA_REQUIRE((stride == 1 || stride == 2) && dil >= 1, "uda_dwconv_fwd: stride must be 1 or 2");
+    UDA_REQUIRE(border_mode == 0 || (border_mode == 1 && src->shift), "uda_dwconv_fwd: border_mode 1 needs shift");
+    DwArgs a;
+    a.src = *src;
+    a.w9c = w9c;
+    a.stride = stride; a.dil = dil; a.border_mode = border_mode;
+    a.Ho = (src->H - 1) / stride + 1;
+    a.Wo = (src->W - 1) / stride + 1;
+    a.y = y; a.ldy = ldy; a.dy = nullptr; a.lddy = 0;
+    const int64_t Pout = (int64_t)src->N * a.Ho * a.Wo;
+    const int nwg = uda_cdiv(Pout, dw_pixels_per_wg(src->C, DW_ITER_FWD));
+    a.part = nullptr;
+    if (stats) {
+        UDA_REQUIRE(workspace && workspace_bytes >= (uint64_t)nwg * 2 * src->C * sizeof(float), "uda_dwconv_fwd: workspace too small");
+        a.part = workspace;
+    }
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
+    UDA_LAUNCH_CHECK("dwconv_fwd");
+    if (stats) return uda_reduce_partials(a.part, nwg, 2 * src->C, stats, st);
+    return 0;
+}
+
+extern "C" int uda_dwconv_dgrad(const float* dy, int64_t lddy, const float* w9c, int C, int stride, int dil,
+                                int N, int H, int W, float* dx, int64_t lddx, void* stream) {
+    UDA_REQUIRE(dy && w9c && dx && uda_aligned16(dy) && uda_aligned16(dx) && uda_aligned16(w9c), "uda_dwconv_dgrad: pointers must be 16-byte aligned");
+    UDA_REQUIRE(C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddy >= C && lddx >= C, "uda_dwconv_dgrad: C and lds must be multiples of 4");
+    UDA_REQUIRE((stride == 1 || stride == 2) && dil >= 1 && N > 0 && H > 0 && W > 0, "uda_dwconv_dgrad: bad geometry");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, lddy, w9c, C, stride, dil,
+                       N, H, W, Ho, Wo, dx, lddx);
+    UDA_LAUNCH_CHECK("dwconv_dgrad");
+    return 0;
+}
+
+extern "C" int uda_dwconv_wgrad(const uda_src_t* src, const float* dy, int64_t lddy, int stride, int dil,
+                                int border_mode, float* dw, float* workspace, uint64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = dw_check(src, "uda_dwconv_wgrad")) return e;
+    UDA_REQUIRE(dy && uda_aligned16(dy) && lddy % 4 == 0 && lddy >= src->C && dw, "uda_dwconv_wgrad: bad pointers");
+    UDA_REQUIRE((stride == 1 || stride == 2) && dil >= 1, "uda_dwconv_wgrad: stride must be 1 or 2");
+    UDA_REQUIRE(border_mode == 0 || (border_mode == 1 && src->shift), "uda_dwconv_wgrad: border_mode 1 needs shift");
+    DwArgs a;
+    a.src = *src;
+    a.w9c = nullptr;
+    a.stride = stride; a.dil = dil; a.border_mode = border_mode;
+    a.Ho = (src->H - 1) / stride + 1;
+    a.Wo = (src->W - 1) / stride + 1;
+    a.y = nullptr; a.ldy = 0; a.dy = dy; a.lddy = lddy;
+    const int C = src->C;
+    const int64_t Pout = (int64_t)src->N * a.Ho * a.Wo;
+    const int nwg = uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED));
+    const uint64_t need = (uint64_t)nwg * 9 * C * sizeof(float) + 9 * C * sizeof(double);
+    UDA_REQUIRE(workspace && workspace_bytes >= need, "uda_dwconv_wgrad: workspace too small");
+    double* sums = reinterpret_cast<double*>(workspace);          // [9][C] first (8-byte aligned)
+    a.part = workspace + 2 * 9 * C;
+    (void)hipMemsetAsync(sums, 0, 9 * C * sizeof(double), st);
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+    UDA_LAUNCH_CHECK("dwconv_wgrad");
+    if (int e = uda_reduce_partials(a.part, nwg, 9 * C, sums, st)) return e;
+    hipLaunchKernelGGL(dw_wgrad_store_kernel, dim3(uda_cdiv(9 * C, 256)), dim3(256), 0, st, sums, C, dw);
+    UDA_LAUNCH_CHECK("dw_wgrad_store");
+    return 0;
+}
+
+// ==========================================================================================
+// Stem: 3x3 stride 2 pad 1, 3 -> 32, NCHW image -> NHWC.  8 lanes (4 channels each) per output
+// pixel: a wave writes 8 pixels x 128 B contiguous; the 27-tap window is re-read from L1.
+struct StemArgs {
+    const float* x;   // [N][3][H][W]
+    int N, H, W, Ho, Wo;
+    const float* w;   // [32][3][3][3]
+    float* y;
+    int64_t ldy;
+    float* part;      // [nWG][2][32]
+    const float* dy;
+    int64_t lddy;
+};
+
+#define STEM_PIX_PER_WG 256   // 32 pixels per pass x 8 passes
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
+    __shared__ float wsm[27 * 32];     // [tap][co]
+    __shared__ float red[32 * 2 * 32];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 27 * 32; e += 256) wsm[e] = a.w[(e % 32) * 27 + e / 32];
+    __syncthreads();
+    const int cg = tid & 7, pl = tid >> 3, c0 = cg * 4;
+    const int64_t Pout = (int64_t)a.N * a.Ho * a.Wo;
+    const int64_t plane = (int64_t)a.H * a.W;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int it = 0; it < 8; ++it) {
+        const int64_t po = (int64_t)blockIdx.x * STEM_PIX_PER_WG + it * 32 + pl;
+        if (po >= Pout) continue;
+        const int ow = (int)(po % a.Wo), oh = (int)((po / a.Wo) % a.Ho), n = (int)(po / ((int64_t)a.Wo * a.Ho));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh * 2 - 1 + kh;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow * 2 - 1 + kw;
+                    float v = 0.f;
+                    if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.x[((int64_t)n * 3 + ci) * plane + (int64_t)ih * a.W + iw];
+                    const float4 ww = uda_ld4(&wsm[(ci * 9 + kh * 3 + kw) * 32 + c0]);
+                    acc.x += ww.x * v; acc.y += ww.y * v; acc.z += ww.z * v; acc.w += ww.w * v;
+                }
+            }
+        uda_st4(a.y + po * a.ldy + c0, acc);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+    }
+    if (a.part == nullptr) return;
+    uda_st4(&red[(pl * 2 + 0) * 32 + c0], s1);
+    uda_st4(&red[(pl * 2 + 1) * 32 + c0], s2);
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+        for (int p = 0; p < 32; ++p) t += red[p * 64 + tid];
+        a.part[(int64_t)blockIdx.x * 64 + tid] = t;
+    }
+}
+
+// dw[co][ci][kh][kw] partials: thread = (co = tid&31, tap group tg = tid>>5 -> taps tg, tg+8, tg+16, tg+24)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
+    __shared__ float xs[32][28];     // per pass: 32 pixels x 27 taps
+    __shared__ float gs[32][33];     // 32 pixels x 32 channels
+    const int tid = threadIdx.x, co = tid & 31, tg = tid >> 5;
+    const int64_t Pout = (int64_t)a.N * a.Ho * a.Wo;
+    const int64_t plane = (int64_t)a.H * a.W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < 8; ++it) {
+        const int64_t pbase = (int64_t)blockIdx.x * STEM_PIX_PER_WG + it * 32;
+        __syncthreads();
+        for (int e = tid; e < 32 * 27; e += 256) {
+            const int pp = e / 27, tap = e % 27;
+            const int64_t po = pbase + pp;
+            float v = 0.f;
+            if (po < Pout) {
+                const int ow = (int)(po % a.Wo), oh = (int)((po / a.Wo) % a.Ho), n = (int)(po / ((int64_t)a.Wo * a.Ho));
+                const int ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.x[((int64_t)n * 3 + ci) * plane + (int64_t)ih * a.W + iw];
+            }
+            xs[pp][tap] = v;
+        }
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int pp = e >> 5, c = e & 31;
+            const int64_t po = pbase + pp;
+            gs[pp][c] = po < Pout ? a.dy[po * a.lddy + c] : 0.f;
+        }
+        __syncthreads();
+        for (int pp = 0; pp < 32; ++pp) {
+            const float g = gs[pp][co];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tap = tg + 8 * q;
+                if (tap < 27) acc[q] += g * xs[pp][tap];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tap = tg + 8 * q;
+        if (tap < 27) a.part[(int64_t)blockIdx.x * 864 + co * 27 + tap] = acc[q];
+    }
+}
+
+__global__ void cast_d2f_kernel(const double* __restrict__ in, int n, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = (float)in[e];
+}
+
+extern "C" uint64_t uda_stem_workspace_bytes(int64_t Pout) {
+    return (uint64_t)uda_cdiv(Pout, STEM_PIX_PER_WG) * 864 * sizeof(float) + 864 * sizeof(double);
+}
+
+extern "C" int uda_stem_fwd(const float* x, int N, int H, int W, const float* w, float* y, int64_t ldy,
+                            double* stats, float* workspace, uint64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    UDA_REQUIRE(x && w && y && uda_aligned16(y) && ldy % 4 == 0 && ldy >= 32 && N > 0 && H > 1 && W > 1, "uda_stem_fwd: bad args");
+    StemArgs a;
+    a.x = x; a.N = N; a.H = H; a.W = W;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.w = w; a.y = y; a.ldy = ldy; a.dy = nullptr; a.lddy = 0;
+    const int64_t Pout = (int64_t)N * a.Ho * a.Wo;
+    const int nwg = uda_cdiv(Pout, STEM_PIX_PER_WG);
+    a.part = nullptr;
+    if (stats) {
+        UDA_REQUIRE(workspace && workspace_bytes >= (uint64_t)nwg * 64 * sizeof(float), "uda_stem_fwd: workspace too small");
+        a.part = workspace;
+    }
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
+    UDA_LAUNCH_CHECK("stem_fwd");
+    if (stats) return uda_reduce_partials(a.part, nwg, 64, stats, st);
+    return 0;
+}
+
+extern "C" int uda_stem_wgrad(const float* x, int N, int H, int W, const float* dy, int64_t lddy, float* dw,
+                              float* workspace, uint64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    UDA_REQUIRE(x && dy && dw && lddy >= 32 && N > 0 && H > 1 && W > 1, "uda_stem_wgrad: bad args");
+    StemArgs a;
+    a.x = x; a.N = N; a.H = H; a.W = W;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.w = nullptr; a.y = nullptr; a.ldy = 0; a.dy = dy; a.lddy = lddy;
+    const int64_t Pout = (int64_t)N * a.Ho * a.Wo;
+    const int nwg = uda_cdiv(Pout, STEM_PIX_PER_WG);
+    UDA_REQUIRE(workspace && workspace_bytes >= uda_stem_workspace_bytes(Pout), "uda_stem_wgrad: workspace too small");
+    double* sums = reinterpret_cast<double*>(workspace);
+    a.part = workspace + 2 * 864;
+    (void)hipMemsetAsync(sums, 0, 864 * sizeof(double), st);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+    UDA_LAUNCH_CHECK("stem_wgrad");
+    if (int e = uda_reduce_partials(a.part, nwg, 864, sums, st)) return e;
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3(uda_cdiv(864, 256)), dim3(256), 0, st, sums, 864, dw);
+    UDA_LAUNCH_CHECK("stem_wgrad_store");
+    return 0;
+}

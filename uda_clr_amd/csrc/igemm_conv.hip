@@ -1,0 +1,607 @@
+// FP32-MFMA implicit-GEMM convolution for gfx950 (stride 1, 1x1 / 3x3, any dilation), NHWC.
+//
+//   y[p, co] = bias[co] + addend[p, co] + sum_k A(p, k) * Wt[co, k],      k = t*Kc + ci
+//   A(p, k)  = u(p + off_t, ci)  (prologue-transformed input, 0 outside the image / ci >= C)
+//
+// Roofline: MFMA-bound for the decoder / ASPP 3x3 convs (560 / 284 FLOP per byte) on
+// v_mfma_f32_32x32x2_f32 (exact fp32, 157.3 TF peak, 64 cycles per instruction per SIMD); the
+// backbone 1x1 convs are HBM-bound and use the narrow-N configurations.
+//
+// Work decomposition (wave64, 4 waves = 256 threads per workgroup, one wave per SIMD):
+//   workgroup tile BM x BN = (32*TM*WM) x (32*TN*WN) outputs, K walked in chunks of BK = 32.
+//   Both operand tiles are staged global -> registers -> LDS as [row][BK+4] fp32 (row stride 36
+//   dwords: conflict-free for the 16-lane groups of ds_read_b128).  The next chunk's global loads
+//   are issued before the MFMAs of the current chunk (async-STAGE split, guide T14) and the BN
+//   affine / ReLU / dropout prologue runs in registers just before the LDS write.
+//   k-permutation: inside each group of 8 k, lane half h supplies k = 8g + 4h + s to MFMA step s
+//   for BOTH operands, so one ds_read_b128 per operand row feeds 4 MFMAs.
+//   Tiles are ordered n-fastest and XCD-chunked (uda_xcd_remap) so the two N tiles of a pixel
+//   tile and spatially adjacent pixel tiles share one XCD's L2.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKArgs {
+    uda_src_t src;
+    const float* w;
+    int Cout, ksize, dil, Kc, Ktot;
+    const float* bias;
+    const float* addend;
+    int64_t ld_add;
+    float* y;
+    int64_t ldy;
+    float* part;   // [nMt][2][Cout] or null
+    int nMt, nNt;
+};
+
+#define IG_BK 32
+#define IG_LD 36
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * IG_LD];
+    float* As = smem;
+    float* Bs = smem + BM * IG_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lid = uda_xcd_remap(blockIdx.x, a.nMt * a.nNt);
+    const int mt = lid / a.nNt, nt = lid % a.nNt;
+    const int H = a.src.H, W = a.src.W, C = a.src.C;
+    const int64_t P = (int64_t)a.src.N * H * W;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+
+    // ---- loader mapping: row = (tid>>3) + 32*i, 4 consecutive k at kv
+    const int lrow = tid >> 3, kv = (tid & 7) * 4;
+    int ph[A_IT], pw[A_IT];
+    bool pok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int64_t p = m0 + lrow + 32 * i;
+        pok[i] = p < P;
+        const int64_t q = pok[i] ? p : 0;
+        pw[i] = (int)(q % W);
+        ph[i] = (int)((q / W) % H);
+    }
+
+    float4 areg[A_IT], breg[B_IT];
+    uint32_t amask[A_IT];
+    unsigned aok = 0;           // bit i: areg[i] holds a real load (else zero)
+    Xf4 xf;
+    int c_ci = 0;
+    bool c_kval = false;
+
+    auto issue = [&](int chunk) {
+        const int k0 = chunk * IG_BK + kv;
+        c_kval = k0 < a.Ktot;
+        int t = 0, ci = k0;
+        if (a.ksize == 3) {
+            t = k0 / a.Kc;
+            ci = k0 - t * a.Kc;
+        }
+        c_ci = ci;
+        int dh = 0, dw = 0;
+        if (a.ksize == 3) {
+            dh = (t / 3 - 1) * a.dil;
+            dw = (t % 3 - 1) * a.dil;
+        }
+        uda_load_xf4(xf, a.src.scale, a.src.shift, ci, c_kval ? C : 0);
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int hh = ph[i] + dh, ww = pw[i] + dw;
+            const bool ok = c_kval && pok[i] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            amask[i] = 0x01010101u;
+            if (ok) {
+                const int64_t q = m0 + lrow + 32 * i + (int64_t)dh * W + dw;
+                areg[i] = uda_ld4(a.src.x + q * a.src.ldx + ci);
+                if (a.src.mask) amask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + q * a.src.ldm + ci);
+                aok |= 1u << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + lrow + 32 * i;
+            breg[i] = (c_kval && n < a.Cout) ? uda_ld4(a.w + (int64_t)n * a.Ktot + k0)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    auto stage = [&]() {
+        const bool has_xf = a.src.scale != nullptr;
+        const int act = a.src.act;
+        const float ms = a.src.mask_scale;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            const bool ok = (aok >> i) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j];
+                if (has_xf) u = u * xf.sc[j] + xf.sh[j];
+                u = uda_act(u, act);
+                if (a.src.mask) u *= ((amask[i] >> (8 * j)) & 0xffu) ? ms : 0.f;
+                v[j] = (ok && (c_ci + j) < C) ? u : 0.f;
+            }
+            uda_st4(&As[(lrow + 32 * i) * IG_LD + kv], make_float4(v[0], v[1], v[2], v[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) uda_st4(&Bs[(lrow + 32 * i) * IG_LD + kv], breg[i]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (a.Ktot + IG_BK - 1) / IG_BK;
+    const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31);
+    const int koff = 4 * (lane >> 5);
+
+    issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();            // every wave finished reading the previous chunk
+        stage();
+        __syncthreads();
+        if (c + 1 < nchunks) issue(c + 1);   // in flight under the MFMAs below
+#pragma unroll
+        for (int g = 0; g < IG_BK / 8; ++g) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = uda_ld4(&As[(arow + 32 * i) * IG_LD + g * 8 + koff]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + g * 8 + koff]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int colb = n0 + wn * TN * 32 + (lane & 31);
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        s1[j] = 0.f;
+        s2[j] = 0.f;
+        const int col = colb + 32 * j;
+        const bool cok = col < a.Cout;
+        const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * TM * 32 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cok && row < P) {
+                    float v = acc[i][j][r] + bv;
+                    s1[j] += v;
+                    s2[j] += v * v;
+                    if (a.addend) v += a.addend[row * a.ld_add + col];
+                    a.y[row * a.ldy + col] = v;
+                }
+            }
+        }
+    }
+    if (a.part) {   // per-tile BN statistics: combine lane halves, then the WM waves through LDS
+        __syncthreads();
+        float* red = smem;   // [WM][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+            if (lane < 32) {
+                const int cl = wn * TN * 32 + 32 * j + lane;
+                red[(wm * 2 + 0) * BN + cl] = t1;
+                red[(wm * 2 + 1) * BN + cl] = t2;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 256) {
+            const int qd = e / BN, cl = e % BN;
+            if (n0 + cl < a.Cout) {
+                float t = 0.f;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) t += red[(m * 2 + qd) * BN + cl];
+                a.part[((int64_t)mt * 2 + qd) * a.Cout + n0 + cl] = t;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[col] += sum_rows part[row][col]   (double accumulation; rows split over blockIdx.y)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nrows, int ncols,
+                                       int rows_per_seg, double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_seg;
+    const int r1 = min(nrows, r0 + rows_per_seg);
+    double s = 0.0;
+    if (col < ncols)
+        for (int r = r0 + rg; r < r1; r += 4) s += (double)part[(int64_t)r * ncols + col];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < ncols) atomicAdd(&out[col], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hipStream_t st) {
+    int segs = nrows / 64;
+    if (segs < 1) segs = 1;
+    if (segs > 64) segs = 64;
+    const int rps = (nrows + segs - 1) / segs;
+    dim3 grid(uda_cdiv(ncols, 64), uda_cdiv(nrows, rps));
+    hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, st, part, nrows, ncols, rps, out);
+    UDA_LAUNCH_CHECK("reduce_partials");
+    return 0;
+}
+
+static int check_src(const uda_src_t& s, const char* who) {
+    UDA_REQUIRE(s.x && uda_aligned16(s.x), "%s: src.x must be 16-byte aligned", who);
+    UDA_REQUIRE(s.ldx % 4 == 0 && s.ldx >= ((s.C + 3) / 4) * 4, "%s: src.ldx=%lld must be a multiple of 4 and >= round4(C=%d)",
+                who, (long long)s.ldx, s.C);
+    UDA_REQUIRE(s.N > 0 && s.H > 0 && s.W > 0 && s.C > 0, "%s: bad src dims", who);
+    UDA_REQUIRE((s.scale == nullptr) == (s.shift == nullptr), "%s: scale/shift must come together", who);
+    if (s.mask) UDA_REQUIRE(s.ldm % 4 == 0 && (reinterpret_cast<uintptr_t>(s.mask) & 3u) == 0 && s.ldm >= ((s.C + 3) / 4) * 4,
+                            "%s: mask must be 4-byte aligned with ldm %% 4 == 0", who);
+    return 0;
+}
+
+extern "C" uint64_t uda_conv_workspace_bytes(int64_t P, int Cout) {
+    return (uint64_t)uda_cdiv(P, 128) * 2u * (uint64_t)Cout * sizeof(float);
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static_assert(BM == 128, "stats partial layout assumes 128-pixel tiles");
+    k.nMt = uda_cdiv(P, BM);
+    k.nNt = uda_cdiv(k.Cout, BN);
+    hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
+    UDA_LAUNCH_CHECK("igemm_conv");
+    return 0;
+}
+
+extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    UDA_REQUIRE(a != nullptr, "uda_conv_fwd: null args");
+    if (int e = check_src(a->src, "uda_conv_fwd")) return e;
+    UDA_REQUIRE(a->ksize == 1 || a->ksize == 3, "uda_conv_fwd: ksize must be 1 or 3");
+    UDA_REQUIRE(a->Cout > 0 && a->dil >= 1 && a->y && a->w, "uda_conv_fwd: bad args");
+    UDA_REQUIRE(uda_aligned16(a->w), "uda_conv_fwd: weights must be 16-byte aligned");
+    UDA_REQUIRE(a->ldy >= a->Cout, "uda_conv_fwd: ldy < Cout");
+    const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
+    ConvKArgs k;
+    k.src = a->src;
+    k.w = a->w;
+    k.Cout = a->Cout;
+    k.ksize = a->ksize;
+    k.dil = a->dil;
+    k.Kc = ((a->src.C + 3) / 4) * 4;
+    k.Ktot = a->ksize * a->ksize * k.Kc;
+    k.bias = a->bias;
+    k.addend = a->addend;
+    k.ld_add = a->ld_add;
+    k.y = a->y;
+    k.ldy = a->ldy;
+    k.part = nullptr;
+    if (a->stats) {
+        UDA_REQUIRE(a->workspace && a->workspace_bytes >= uda_conv_workspace_bytes(P, a->Cout),
+                    "uda_conv_fwd: workspace too small for the BN statistics partials");
+        k.part = a->workspace;
+    }
+    int e;
+    if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
+    else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
+    else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
+    else e = launch_conv<2, 2, 2, 2>(k, P, st);
+    if (e) return e;
+    if (a->stats) return uda_reduce_partials(k.part, k.nMt, 2 * a->Cout, a->stats, st);
+    return 0;
+}
+
+// ==========================================================================================
+// Weight gradient: dw[co][j] = sum_p dy[p, co] * A(p, j),  j = t*Kc + ci; reduction over pixels.
+// Operands are staged [pixel][row] (row fastest) so the MFMA operand reads are plain ds_read_b32
+// of 32 consecutive dwords.  The pixel range is split over blockIdx.y; every split writes its
+// own fp32 slab and a second kernel sums the slabs (bitwise reproducible, no float atomics).
+struct WgradKArgs {
+    uda_src_t src;
+    const float* dy;
+    int64_t lddy;
+    int Cout, ksize, dil, Kc, Jtot;
+    float* slab;      // [S][Cout][Jtot]
+    int nCot, nJt, chunks_per_split, nchunks;
+};
+
+#define WG_BKP 32
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int AV = BM / 4, BV = BN / 4;                 // float4 per staged row
+    constexpr int ARPP = 256 / AV, BRPP = 256 / BV;          // pixel rows per pass
+    constexpr int APASS = WG_BKP / ARPP, BPASS = WG_BKP / BRPP;
+    __shared__ __attribute__((aligned(16))) float smem[WG_BKP * (BM + BN)];
+    float* As = smem;                    // [32][BM]
+    float* Bs = smem + WG_BKP * BM;      // [32][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int cot = blockIdx.x / a.nJt, jt = blockIdx.x % a.nJt;
+    const int split = blockIdx.y;
+    const int H = a.src.H, W = a.src.W, C = a.src.C;
+    const int64_t P = (int64_t)a.src.N * H * W;
+
+    const int acv = (tid % AV) * 4, apr = tid / AV;
+    const int co = cot * BM + acv;
+    const int bjv = (tid % BV) * 4, bpr = tid / BV;
+    const int j0 = jt * BN + bjv;
+    const bool jok = j0 < a.Jtot;
+    int t = 0, ci = j0;
+    if (a.ksize == 3 && jok) {
+        t = j0 / a.Kc;
+        ci = j0 - t * a.Kc;
+    }
+    int dh = 0, dw = 0;
+    if (a.ksize == 3) {
+        dh = (t / 3 - 1) * a.dil;
+        dw = (t % 3 - 1) * a.dil;
+    }
+    Xf4 xf;
+    uda_load_xf4(xf, a.src.scale, a.src.shift, ci, jok ? C : 0);
+    const bool has_xf = a.src.scale != nullptr;
+    const int act = a.src.act;
+    const float ms = a.src.mask_scale;
+
+    float4 areg[APASS], breg[BPASS];
+    uint32_t bmask[BPASS];
+    unsigned bok = 0;
+
+    auto issue = [&](int chunk) {
+        const int64_t p0 = (int64_t)chunk * WG_BKP;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int64_t p = p0 + apr + i * ARPP;
+            areg[i] = (p < P && co < a.Cout) ? uda_ld4(a.dy + p * a.lddy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        bok = 0;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int64_t p = p0 + bpr + i * BRPP;
+            breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bmask[i] = 0x01010101u;
+            if (jok && p < P) {
+                const int w0 = (int)(p % W), h0 = (int)((p / W) % H);
+                const int hh = h0 + dh, ww = w0 + dw;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                    const int64_t q = p + (int64_t)dh * W + dw;
+                    breg[i] = uda_ld4(a.src.x + q * a.src.ldx + ci);
+                    if (a.src.mask) bmask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + q * a.src.ldm + ci);
+                    bok |= 1u << i;
+                }
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co + j >= a.Cout) v[j] = 0.f;
+            uda_st4(&As[(apr + i * ARPP) * BM + acv], make_float4(v[0], v[1], v[2], v[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            float v[4] = {breg[i].x, breg[i].y, breg[i].z, breg[i].w};
+            const bool ok = (bok >> i) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j];
+                if (has_xf) u = u * xf.sc[j] + xf.sh[j];
+                u = uda_act(u, act);
+                if (a.src.mask) u *= ((bmask[i] >> (8 * j)) & 0xffu) ? ms : 0.f;
+                v[j] = (ok && (ci + j) < C) ? u : 0.f;
+            }
+            uda_st4(&Bs[(bpr + i * BRPP) * BN + bjv], make_float4(v[0], v[1], v[2], v[3]));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int c0 = split * a.chunks_per_split;
+    const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+    const int acol = wm * TM * 32 + (lane & 31), bcol = wn * TN * 32 + (lane & 31);
+    const int kh = lane >> 5;
+    if (c0 < c1) issue(c0);
+    for (int c = c0; c < c1; ++c) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (c + 1 < c1) issue(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < WG_BKP / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + kh) * BM + acol + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kk + kh) * BN + bcol + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* slab = a.slab + (int64_t)split * a.Cout * a.Jtot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = jt * BN + wn * TN * 32 + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cot * BM + wm * TM * 32 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a.Cout && col < a.Jtot) slab[(int64_t)row * a.Jtot + col] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[co][ci][t] = sum_s slab[s][co][t*Kc + ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int S, int Cout, int Cin, int T,
+                                    int Kc, float* __restrict__ dw) {
+    const int64_t total = (int64_t)Cout * T * Cin;
+    const int64_t stride = (int64_t)Cout * T * Kc;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(e % Cin);
+        const int t = (int)((e / Cin) % T);
+        const int co = (int)(e / ((int64_t)Cin * T));
+        const float* src = slab + ((int64_t)co * T + t) * Kc + ci;
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += src[k * stride];
+        dw[((int64_t)co * Cin + ci) * T + t] = s;
+    }
+}
+
+struct WgradPlan {
+    int bm, bn, nCot, nJt, S, cps, nchunks;
+};
+
+static WgradPlan wgrad_plan(int64_t P, int Cout, int Cin, int ksize) {
+    WgradPlan p;
+    const int Kc = ((Cin + 3) / 4) * 4, J = ksize * ksize * Kc;
+    const int cm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    const int cn = J <= 32 ? 32 : (J <= 64 ? 64 : 128);
+    if (cm == 128 && cn == 32) { p.bm = 128; p.bn = 32; }
+    else if (cm == 32 && cn == 128) { p.bm = 32; p.bn = 128; }
+    else if (cm <= 64 && cn <= 64) { p.bm = 64; p.bn = 64; }
+    else { p.bm = 128; p.bn = 128; }
+    p.nCot = uda_cdiv(Cout, p.bm);
+    p.nJt = uda_cdiv(J, p.bn);
+    p.nchunks = uda_cdiv(P, WG_BKP);
+    int S = 1024 / (p.nCot * p.nJt);
+    if (S > p.nchunks / 4) S = p.nchunks / 4;
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    p.cps = uda_cdiv(p.nchunks, S);
+    p.S = uda_cdiv(p.nchunks, p.cps);
+    return p;
+}
+
+extern "C" uint64_t uda_conv_wgrad_workspace_bytes(int64_t P, int Cout, int Cin, int ksize) {
+    const WgradPlan p = wgrad_plan(P, Cout, Cin, ksize);
+    const int Kc = ((Cin + 3) / 4) * 4;
+    return (uint64_t)p.S * Cout * ksize * ksize * Kc * sizeof(float);
+}
+
+extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    UDA_REQUIRE(a != nullptr, "uda_conv_wgrad: null args");
+    if (int e = check_src(a->src, "uda_conv_wgrad")) return e;
+    UDA_REQUIRE(a->ksize == 1 || a->ksize == 3, "uda_conv_wgrad: ksize must be 1 or 3");
+    UDA_REQUIRE(a->dy && uda_aligned16(a->dy) && a->lddy % 4 == 0 && a->lddy >= ((a->Cout + 3) / 4) * 4,
+                "uda_conv_wgrad: dy must be 16-byte aligned with lddy %% 4 == 0 and >= round4(Cout)");
+    const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
+    const WgradPlan p = wgrad_plan(P, a->Cout, a->src.C, a->ksize);
+    UDA_REQUIRE(a->workspace && a->workspace_bytes >= uda_conv_wgrad_workspace_bytes(P, a->Cout, a->src.C, a->ksize),
+                "uda_conv_wgrad: workspace too small");
+    WgradKArgs k;
+    k.src = a->src;
+    k.dy = a->dy;
+    k.lddy = a->lddy;
+    k.Cout = a->Cout;
+    k.ksize = a->ksize;
+    k.dil = a->dil;
+    k.Kc = ((a->src.C + 3) / 4) * 4;
+    k.Jtot = a->ksize * a->ksize * k.Kc;
+    k.slab = a->workspace;
+    k.nCot = p.nCot;
+    k.nJt = p.nJt;
+    k.chunks_per_split = p.cps;
+    k.nchunks = p.nchunks;
+    dim3 grid(p.nCot * p.nJt, p.S);
+    if (p.bm == 128 && p.bn == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, k);
+    else if (p.bm == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, k);
+    else if (p.bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 4, 1>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 1, 4>), grid, dim3(256), 0, st, k);
+    UDA_LAUNCH_CHECK("igemm_wgrad");
+    const int T = a->ksize * a->ksize;
+    const int64_t total = (int64_t)a->Cout * T * a->src.C;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(uda_cdiv(total, 256) > 2048 ? 2048 : uda_cdiv(total, 256)), dim3(256), 0, st,
+                       k.slab, p.S, a->Cout, a->src.C, T, k.Kc, a->dw);
+    UDA_LAUNCH_CHECK("wgrad_reduce");
+    return 0;
+}
+
+// ==========================================================================================
+// weight re-layouts
+__global__ void relayout_ohwi_kernel(const float* __restrict__ w, int O, int I, int T, int Kc, float* __restrict__ out) {
+    const int64_t total = (int64_t)O * T * Kc;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(e % Kc), t = (int)((e / Kc) % T), o = (int)(e / ((int64_t)Kc * T));
+        out[e] = ci < I ? w[((int64_t)o * I + ci) * T + t] : 0.f;
+    }
+}
+__global__ void relayout_dgrad_kernel(const float* __restrict__ w, int O, int I, int T, int Oc, float* __restrict__ out) {
+    const int64_t total = (int64_t)I * T * Oc;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e % Oc), t = (int)((e / Oc) % T), ci = (int)(e / ((int64_t)Oc * T));
+        out[e] = o < O ? w[((int64_t)o * I + ci) * T + (T - 1 - t)] : 0.f;
+    }
+}
+__global__ void relayout_dw_kernel(const float* __restrict__ w, int C, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 9 * C) out[e] = w[(e % C) * 9 + e / C];
+}
+
+static inline int grid_for(int64_t total) {
+    int g = uda_cdiv(total, 256);
+    return g > 4096 ? 4096 : (g < 1 ? 1 : g);
+}
+
+extern "C" int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out, void* stream) {
+    UDA_REQUIRE(w && out && O > 0 && I > 0 && (k == 1 || k == 3), "uda_relayout_ohwi: bad args");
+    const int Kc = ((I + 3) / 4) * 4;
+    hipLaunchKernelGGL(relayout_ohwi_kernel, dim3(grid_for((int64_t)O * k * k * Kc)), dim3(256), 0, (hipStream_t)stream,
+                       w, O, I, k * k, Kc, out);
+    UDA_LAUNCH_CHECK("relayout_ohwi");
+    return 0;
+}
+extern "C" int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* stream) {
+    UDA_REQUIRE(w && out && O > 0 && I > 0 && (k == 1 || k == 3), "uda_relayout_dgrad: bad args");
+    const int Oc = ((O + 3) / 4) * 4;
+    hipLaunchKernelGGL(relayout_dgrad_kernel, dim3(grid_for((int64_t)I * k * k * Oc)), dim3(256), 0, (hipStream_t)stream,
+                       w, O, I, k * k, Oc, out);
+    UDA_LAUNCH_CHECK("relayout_dgrad");
+    return 0;
+}
+extern "C" int uda_relayout_dw(const float* w, int C, float* out, void* stream) {
+    UDA_REQUIRE(w && out && C > 0, "uda_relayout_dw: bad args");
+    hipLaunchKernelGGL(relayout_dw_kernel, dim3(uda_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, w, C, out);
+    UDA_LAUNCH_CHECK("relayout_dw");
+    return 0;
+}

@@ -1,0 +1,299 @@
+// Bilinear (align_corners=True) resampling, global average pooling / row broadcast and the
+// dropout keep-mask generator.  All HBM-bound gather/stream kernels.
+//   upsample_*        NHWC -> NHWC (decoder.py:50, 32x32 -> 128x128 x 256 ch into a channel window)
+//   head_upsample_*   NHWC (C<=4) -> contiguous NCHW (deeplabv3.py:39-40, 128^2 -> 512^2 logits)
+//   gap / broadcast   aspp.py:55-58,70-71 (image-level branch) and their adjoints
+// The backward kernels GATHER (every input pixel re-derives, with the forward's own index
+// arithmetic, which outputs touched it) - deterministic, no float atomics.
+#include "common.h"
+
+// PyTorch's area_pixel_compute_source_index for align_corners=True: src = scale * dst (fp32)
+__device__ __forceinline__ void bil_src(int o, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    const float real = scale * (float)o;
+    i0 = (int)real;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = real - (float)i0;
+    l0 = 1.f - l1;
+}
+static inline float bil_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int h, int w,
+                                                           int C, float* __restrict__ out, int64_t ldo, int H, int W,
+                                                           float sh, float sw) {
+    const int G = C >> 2;
+    const int64_t total = (int64_t)N * H * W * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int64_t p = e / G;
+        const int ow = (int)(p % W), oh = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        int h0, h1, w0, w1;
+        float lh0, lh1, lw0, lw1;
+        bil_src(oh, sh, h, h0, h1, lh0, lh1);
+        bil_src(ow, sw, w, w0, w1, lw0, lw1);
+        const float* b = x + (int64_t)n * h * w * ldx + cg * 4;
+        const float4 a00 = uda_ld4(b + ((int64_t)h0 * w + w0) * ldx), a01 = uda_ld4(b + ((int64_t)h0 * w + w1) * ldx);
+        const float4 a10 = uda_ld4(b + ((int64_t)h1 * w + w0) * ldx), a11 = uda_ld4(b + ((int64_t)h1 * w + w1) * ldx);
+        float4 r;
+        r.x = lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
+        r.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
+        r.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
+        r.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
+        uda_st4(out + p * ldo + cg * 4, r);
+    }
+}
+
+// weight with which output index o reads input index i (0 if it does not)
+__device__ __forceinline__ float bil_weight(int o, float scale, int n_in, int i) {
+    int i0, i1;
+    float l0, l1;
+    bil_src(o, scale, n_in, i0, i1, l0, l1);
+    float wgt = 0.f;
+    if (i0 == i) wgt += l0;
+    if (i1 == i) wgt += l1;
+    return wgt;
+}
+// conservative range of outputs that can touch input i
+__device__ __forceinline__ void bil_range(int i, float scale, int n_out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = n_out - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > n_out - 1) hi = n_out - 1;
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, int64_t ldo, int N, int H, int W,
+                                                           int C, float* __restrict__ dx, int64_t ldx, int h, int w,
+                                                           float sh, float sw) {
+    const int G = C >> 2;
+    const int64_t total = (int64_t)N * h * w * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int64_t p = e / G;
+        const int iw = (int)(p % w), ih = (int)((p / w) % h), n = (int)(p / ((int64_t)w * h));
+        int hlo, hhi, wlo, whi;
+        bil_range(ih, sh, H, hlo, hhi);
+        bil_range(iw, sw, W, wlo, whi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            const float wh = bil_weight(oh, sh, h, ih);
+            if (wh == 0.f) continue;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                const float ww = bil_weight(ow, sw, w, iw);
+                if (ww == 0.f) continue;
+                const float4 g = uda_ld4(dout + (((int64_t)n * H + oh) * W + ow) * ldo + cg * 4);
+                const float k = wh * ww;
+                acc.x += k * g.x; acc.y += k * g.y; acc.z += k * g.z; acc.w += k * g.w;
+            }
+        }
+        uda_st4(dx + p * ldx + cg * 4, acc);
+    }
+}
+
+extern "C" int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, float* out, int64_t ldo, int H,
+                                int W, void* stream) {
+    UDA_REQUIRE(x && out && uda_aligned16(x) && uda_aligned16(out) && ldx % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && C > 0 &&
+                    ldx >= C && ldo >= C, "uda_upsample_fwd: C and lds must be multiples of 4, pointers 16-byte aligned");
+    UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "uda_upsample_fwd: bad geometry");
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo, H, W,
+                       bil_scale(h, H), bil_scale(w, W));
+    UDA_LAUNCH_CHECK("upsample_fwd");
+    return 0;
+}
+
+extern "C" int uda_upsample_bwd(const float* dout, int64_t ldo, int N, int H, int W, int C, float* dx, int64_t ldx, int h,
+                                int w, void* stream) {
+    UDA_REQUIRE(dout && dx && uda_aligned16(dout) && uda_aligned16(dx) && ldx % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && C > 0 &&
+                    ldx >= C && ldo >= C, "uda_upsample_bwd: C and lds must be multiples of 4, pointers 16-byte aligned");
+    UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "uda_upsample_bwd: bad geometry");
+    const int64_t total = (int64_t)N * h * w * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, ldo, N, H, W, C, dx, ldx, h, w,
+                       bil_scale(h, H), bil_scale(w, W));
+    UDA_LAUNCH_CHECK("upsample_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_upsample_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int h, int w,
+                                                                int C, float* __restrict__ out, int H, int W, float sh,
+                                                                float sw) {
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(p % W), oh = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        int h0, h1, w0, w1;
+        float lh0, lh1, lw0, lw1;
+        bil_src(oh, sh, h, h0, h1, lh0, lh1);
+        bil_src(ow, sw, w, w0, w1, lw0, lw1);
+        const float* b = x + (int64_t)n * h * w * ldx;
+        for (int c = 0; c < C; ++c) {
+            const float a00 = b[((int64_t)h0 * w + w0) * ldx + c], a01 = b[((int64_t)h0 * w + w1) * ldx + c];
+            const float a10 = b[((int64_t)h1 * w + w0) * ldx + c], a11 = b[((int64_t)h1 * w + w1) * ldx + c];
+            out[(((int64_t)n * C + c) * H + oh) * W + ow] = lh0 * (lw0 * a00 + lw1 * a01) + lh1 * (lw0 * a10 + lw1 * a11);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_upsample_bwd_kernel(const float* __restrict__ dout, int N, int C, int H, int W,
+                                                                float* dx, int64_t ldx, int h, int w, int accumulate,
+                                                                float sh, float sw) {
+    const int64_t total = (int64_t)N * h * w;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int iw = (int)(p % w), ih = (int)((p / w) % h), n = (int)(p / ((int64_t)w * h));
+        int hlo, hhi, wlo, whi;
+        bil_range(ih, sh, H, hlo, hhi);
+        bil_range(iw, sw, W, wlo, whi);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            const float wh = bil_weight(oh, sh, h, ih);
+            if (wh == 0.f) continue;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                const float ww = bil_weight(ow, sw, w, iw);
+                if (ww == 0.f) continue;
+                const float k = wh * ww;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < C) acc[c] += k * dout[(((int64_t)n * C + c) * H + oh) * W + ow];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                float* d = dx + p * ldx + c;
+                *d = accumulate ? (*d + acc[c]) : acc[c];
+            }
+    }
+}
+
+extern "C" int uda_head_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, float* out, int H, int W,
+                                     void* stream) {
+    UDA_REQUIRE(x && out && C >= 1 && C <= 4 && ldx >= C && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "uda_head_upsample_fwd: bad args");
+    int grid = uda_cdiv((int64_t)N * H * W, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(head_upsample_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, H, W,
+                       bil_scale(h, H), bil_scale(w, W));
+    UDA_LAUNCH_CHECK("head_upsample_fwd");
+    return 0;
+}
+
+extern "C" int uda_head_upsample_bwd(const float* dout, int N, int C, int H, int W, float* dx, int64_t ldx, int h, int w,
+                                     int accumulate, void* stream) {
+    UDA_REQUIRE(dout && dx && C >= 1 && C <= 4 && ldx >= C && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "uda_head_upsample_bwd: bad args");
+    int grid = uda_cdiv((int64_t)N * h * w, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(head_upsample_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, N, C, H, W, dx, ldx, h, w,
+                       accumulate, bil_scale(h, H), bil_scale(w, W));
+    UDA_LAUNCH_CHECK("head_upsample_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[n, c] = scale * sum_{pixels of image n} x[p, c];  one workgroup per (image, 256-channel block)
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, int64_t ldx, int HW, int C, float scale,
+                                                  float* __restrict__ out, int64_t ldo) {
+    __shared__ float red[4][64 * 4];
+    const int n = blockIdx.x, cb = blockIdx.y * 256;
+    const int Cb = min(256, C - cb), G = (Cb + 3) >> 2;     // <= 64 groups
+    const int tid = threadIdx.x, cg = tid % 64, pl = tid / 64;   // 4 pixel lanes
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cg < G) {
+        const int c0 = cb + cg * 4;
+        for (int p = pl; p < HW; p += 4) {
+            const float4 v = uda_ld4(x + ((int64_t)n * HW + p) * ldx + c0);
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[pl][cg * 4 + j] = acc[j];
+    __syncthreads();
+    if (tid < Cb) out[(int64_t)n * ldo + cb + tid] = scale * (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+extern "C" int uda_gap_fwd(const float* x, int64_t ldx, int N, int HW, int C, float scale, float* out, int64_t ldo, void* stream) {
+    UDA_REQUIRE(x && out && uda_aligned16(x) && ldx % 4 == 0 && ldx >= ((C + 3) / 4) * 4 && N > 0 && HW > 0 && C > 0 && ldo >= C,
+                "uda_gap_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
+    hipLaunchKernelGGL(gap_kernel, dim3(N, uda_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, HW, C, scale, out, ldo);
+    UDA_LAUNCH_CHECK("gap");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ g, int64_t ldg, int N, int HW, int C,
+                                                             float scale, const float* addend, int64_t ld_add, float* out,
+                                                             int64_t ldo) {
+    const int G = C >> 2;
+    const int64_t total = (int64_t)N * HW * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int64_t p = e / G;
+        const int n = (int)(p / HW);
+        const float4 v = uda_ld4(g + (int64_t)n * ldg + cg * 4);
+        float4 r = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+        if (addend) {
+            const float4 a = uda_ld4(addend + p * ld_add + cg * 4);
+            r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+        }
+        uda_st4(out + p * ldo + cg * 4, r);
+    }
+}
+
+extern "C" int uda_broadcast_rows(const float* g, int64_t ldg, int N, int HW, int C, float scale, const float* addend,
+                                  int64_t ld_add, float* out, int64_t ldo, void* stream) {
+    UDA_REQUIRE(g && out && uda_aligned16(g) && uda_aligned16(out) && ldg % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && C > 0,
+                "uda_broadcast_rows: C and lds must be multiples of 4, pointers 16-byte aligned");
+    if (addend) UDA_REQUIRE(uda_aligned16(addend) && ld_add % 4 == 0, "uda_broadcast_rows: bad addend layout");
+    const int64_t total = (int64_t)N * HW * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, ldg, N, HW, C, scale, addend,
+                       ld_add, out, ldo);
+    UDA_LAUNCH_CHECK("broadcast_rows");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10: one counter -> 16 keep bytes (4 x 32 random bits, one byte-wide compare each).
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, int64_t ldm, int64_t P, int C,
+                                                           uint32_t thresh24, uint64_t seed, uint64_t offset) {
+    const int G = (C + 3) >> 2;
+    const int64_t total = P * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int64_t p = e / G;
+        uint32_t c0 = (uint32_t)e, c1 = (uint32_t)(e >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint32_t rnd[4] = {c0, c1, c2, c3};
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) packed |= ((rnd[j] >> 8) >= thresh24 ? 1u : 0u) << (8 * j);   // keep with prob 1-p
+        *reinterpret_cast<uint32_t*>(mask + p * ldm + cg * 4) = packed;
+    }
+}
+
+extern "C" int uda_dropout_mask(uint8_t* mask, int64_t ldm, int64_t P, int C, float p, uint64_t seed, uint64_t offset, void* stream) {
+    UDA_REQUIRE(mask && (reinterpret_cast<uintptr_t>(mask) & 3u) == 0 && ldm % 4 == 0 && ldm >= ((C + 3) / 4) * 4 && P > 0 && C > 0,
+                "uda_dropout_mask: mask must be 4-byte aligned with ldm %% 4 == 0 and >= round4(C)");
+    UDA_REQUIRE(p >= 0.f && p < 1.f, "uda_dropout_mask: p must be in [0, 1)");
+    const uint32_t thresh24 = (uint32_t)((double)p * 16777216.0);
+    int grid = uda_cdiv(P * ((C + 3) / 4), 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, ldm, P, C, thresh24, seed, offset);
+    UDA_LAUNCH_CHECK("dropout_mask");
+    return 0;
+}

@@ -1,0 +1,370 @@
+"""ctypes bindings of libuda_clr_hip.so (include/uda_clr_hip.h) at the torch-tensor level.
+
+PyTorch is only the owner of device memory and of the current HIP stream here: every method
+checks layouts on the host, passes raw pointers + sizes through the C ABI and launches on
+``torch.cuda.current_stream()``.  There is no fallback: a missing library or a non-GPU tensor
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from .acts import Act, round4
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libuda_clr_hip.so")
+_lib = None
+
+
+class UdaSrc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("N", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("C", C.c_int32), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("act", C.c_int32), ("_pad", C.c_int32), ("mask", C.c_void_p), ("ldm", C.c_int64),
+                ("mask_scale", C.c_float), ("_pad2", C.c_float)]
+
+
+class UdaConvArgs(C.Structure):
+    _fields_ = [("src", UdaSrc), ("w", C.c_void_p), ("Cout", C.c_int32), ("ksize", C.c_int32),
+                ("dil", C.c_int32), ("_pad", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
+                ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+
+
+class UdaWgradArgs(C.Structure):
+    _fields_ = [("src", UdaSrc), ("dy", C.c_void_p), ("lddy", C.c_int64), ("Cout", C.c_int32),
+                ("ksize", C.c_int32), ("dil", C.c_int32), ("_pad", C.c_int32), ("dw", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+
+
+# every symbol declared in include/uda_clr_hip.h: name -> (restype, argtypes)
+_P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
+SYMBOLS = {
+    "uda_last_error": (C.c_char_p, []),
+    "uda_version": (_I, []),
+    "uda_relayout_ohwi": (_I, [_P, _I, _I, _I, _P, _P]),
+    "uda_relayout_dgrad": (_I, [_P, _I, _I, _I, _P, _P]),
+    "uda_relayout_dw": (_I, [_P, _I, _P, _P]),
+    "uda_conv_workspace_bytes": (_U, [_L, _I]),
+    "uda_conv_fwd": (_I, [C.POINTER(UdaConvArgs), _P]),
+    "uda_conv_wgrad_workspace_bytes": (_U, [_L, _I, _I, _I]),
+    "uda_conv_wgrad": (_I, [C.POINTER(UdaWgradArgs), _P]),
+    "uda_dwconv_workspace_bytes": (_U, [_L, _I]),
+    "uda_dwconv_fwd": (_I, [C.POINTER(UdaSrc), _P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
+    "uda_dwconv_dgrad": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "uda_dwconv_wgrad": (_I, [C.POINTER(UdaSrc), _P, _L, _I, _I, _I, _P, _P, _U, _P]),
+    "uda_stem_workspace_bytes": (_U, [_L]),
+    "uda_stem_fwd": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P, _U, _P]),
+    "uda_stem_wgrad": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
+    "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
+    "uda_bn_apply": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
+    "uda_reduce_workspace_bytes": (_U, [_L, _I, _I]),
+    "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P, _U, _P]),
+    "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _U, _P]),
+    "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "uda_bnbwd_apply": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
+    "uda_upsample_fwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
+    "uda_upsample_bwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
+    "uda_head_upsample_fwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "uda_head_upsample_bwd": (_I, [_P, _I, _I, _I, _I, _P, _L, _I, _I, _I, _P]),
+    "uda_gap_fwd": (_I, [_P, _L, _I, _I, _I, _F, _P, _L, _P]),
+    "uda_broadcast_rows": (_I, [_P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _P]),
+    "uda_dropout_mask": (_I, [_P, _L, _L, _I, _F, _U, _U, _P]),
+}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the C-ABI library and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("libuda_clr_hip.so not found at %s - build it with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError -> symbol missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class UdaError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, name="tensor"):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("%s must be a [P, C] row-major view" % name)
+    return t.data_ptr(), t.stride(0)
+
+
+class HipKernels:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load_library()
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise UdaError(self.lib.uda_last_error().decode())
+
+    @staticmethod
+    def _dev(t):
+        if not t.is_cuda:
+            raise UdaError("HIP kernels need device tensors (got %s); there is no CPU fallback" % t.device)
+        if t.dtype not in (torch.float32, torch.float64, torch.uint8):
+            raise UdaError("unsupported dtype %s" % t.dtype)
+
+    def _src(self, a: Act) -> UdaSrc:
+        a.check()
+        self._dev(a.x)
+        s = UdaSrc()
+        s.x, s.ldx = a.x.data_ptr(), a.x.stride(0)
+        s.N, s.H, s.W, s.C = a.N, a.H, a.W, a.C
+        s.scale, s.shift = _ptr(a.scale), _ptr(a.shift)
+        if a.scale is not None:
+            assert a.scale.is_contiguous() and a.shift.is_contiguous() and a.scale.numel() == a.C
+        s.act = a.act
+        if a.mask is not None:
+            s.mask, s.ldm = a.mask.data_ptr(), a.mask.stride(0)
+        else:
+            s.mask, s.ldm = None, 0
+        s.mask_scale = a.mask_scale
+        return s
+
+    @staticmethod
+    def _ws(like, nbytes):
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+    # ------------------------------------------------------------------ weight layouts
+    def relayout_ohwi(self, w):
+        O, I, k, _ = w.shape
+        out = torch.empty(O, k * k, round4(I), dtype=torch.float32, device=w.device)
+        self._ck(self.lib.uda_relayout_ohwi(w.contiguous().data_ptr(), O, I, k, out.data_ptr(), self._stream()))
+        return out
+
+    def relayout_dgrad(self, w):
+        O, I, k, _ = w.shape
+        out = torch.empty(I, k * k, round4(O), dtype=torch.float32, device=w.device)
+        self._ck(self.lib.uda_relayout_dgrad(w.contiguous().data_ptr(), O, I, k, out.data_ptr(), self._stream()))
+        return out
+
+    def relayout_dw(self, w):
+        Cc = w.shape[0]
+        out = torch.empty(9, Cc, dtype=torch.float32, device=w.device)
+        self._ck(self.lib.uda_relayout_dw(w.contiguous().data_ptr(), Cc, out.data_ptr(), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ dense conv
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None):
+        a = UdaConvArgs()
+        a.src = self._src(src)
+        Cout = out.shape[1]
+        assert w.is_contiguous() and tuple(w.shape) == (Cout, ksize * ksize, round4(src.C)), \
+            "weight layout %s does not match conv %dx%d %d->%d" % (tuple(w.shape), ksize, ksize, src.C, Cout)
+        assert out.shape[0] == src.P
+        a.w, a.Cout, a.ksize, a.dil = w.data_ptr(), Cout, ksize, dil
+        a.bias = _ptr(bias)
+        if bias is not None:
+            assert bias.is_contiguous() and bias.numel() == Cout
+        if addend is not None:
+            assert addend.shape == out.shape
+            a.addend, a.ld_add = _mat(addend, "addend")
+        else:
+            a.addend, a.ld_add = None, 0
+        a.y, a.ldy = _mat(out, "out")
+        ws = None
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (2, Cout)
+            ws = self._ws(out, self.lib.uda_conv_workspace_bytes(src.P, Cout))
+            a.stats, a.workspace, a.workspace_bytes = stats.data_ptr(), ws.data_ptr(), ws.numel()
+        else:
+            a.stats, a.workspace, a.workspace_bytes = None, None, 0
+        self._ck(self.lib.uda_conv_fwd(C.byref(a), self._stream()))
+
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw):
+        a = UdaWgradArgs()
+        a.src = self._src(src)
+        Cout = dy.shape[1]
+        assert dy.shape[0] == src.P and dw.is_contiguous() and tuple(dw.shape) == (Cout, src.C, ksize, ksize)
+        a.dy, a.lddy = _mat(dy, "dy")
+        a.Cout, a.ksize, a.dil = Cout, ksize, dil
+        a.dw = dw.data_ptr()
+        ws = self._ws(dy, self.lib.uda_conv_wgrad_workspace_bytes(src.P, Cout, src.C, ksize))
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        self._ck(self.lib.uda_conv_wgrad(C.byref(a), self._stream()))
+
+    # ------------------------------------------------------------------ depthwise
+    def dwconv_fwd(self, src: Act, w9c, stride, dil, border_mode, out, stats=None):
+        s = self._src(src)
+        Ho, Wo = (src.H - 1) // stride + 1, (src.W - 1) // stride + 1
+        assert out.shape == (src.N * Ho * Wo, src.C) and w9c.is_contiguous() and tuple(w9c.shape) == (9, src.C)
+        y, ldy = _mat(out, "out")
+        ws = self._ws(out, self.lib.uda_dwconv_workspace_bytes(out.shape[0], src.C)) if stats is not None else None
+        self._ck(self.lib.uda_dwconv_fwd(C.byref(s), w9c.data_ptr(), stride, dil, border_mode, y, ldy, _ptr(stats),
+                                         _ptr(ws), 0 if ws is None else ws.numel(), self._stream()))
+
+    def dwconv_dgrad(self, dy, w9c, stride, dil, N, H, W, out):
+        Cc = dy.shape[1]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        assert dy.shape[0] == N * Ho * Wo and out.shape == (N * H * W, Cc)
+        g, ldg = _mat(dy, "dy")
+        o, ldo = _mat(out, "out")
+        self._ck(self.lib.uda_dwconv_dgrad(g, ldg, w9c.data_ptr(), Cc, stride, dil, N, H, W, o, ldo, self._stream()))
+
+    def dwconv_wgrad(self, src: Act, dy, stride, dil, border_mode, dw):
+        s = self._src(src)
+        Ho, Wo = (src.H - 1) // stride + 1, (src.W - 1) // stride + 1
+        assert dy.shape == (src.N * Ho * Wo, src.C) and dw.is_contiguous() and dw.numel() == 9 * src.C
+        g, ldg = _mat(dy, "dy")
+        ws = self._ws(dy, self.lib.uda_dwconv_workspace_bytes(dy.shape[0], src.C))
+        self._ck(self.lib.uda_dwconv_wgrad(C.byref(s), g, ldg, stride, dil, border_mode, dw.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), self._stream()))
+
+    # ------------------------------------------------------------------ stem
+    def stem_fwd(self, x, w, out, stats=None):
+        self._dev(x)
+        N, c3, H, W = x.shape
+        assert c3 == 3 and x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (32, 3, 3, 3)
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        assert out.shape == (Po, 32)
+        y, ldy = _mat(out, "out")
+        ws = self._ws(out, self.lib.uda_stem_workspace_bytes(Po)) if stats is not None else None
+        self._ck(self.lib.uda_stem_fwd(x.data_ptr(), N, H, W, w.data_ptr(), y, ldy, _ptr(stats), _ptr(ws),
+                                       0 if ws is None else ws.numel(), self._stream()))
+
+    def stem_wgrad(self, x, dy, dw):
+        N, _, H, W = x.shape
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        assert dy.shape == (Po, 32) and dw.is_contiguous() and dw.numel() == 864
+        g, ldg = _mat(dy, "dy")
+        ws = self._ws(dy, self.lib.uda_stem_workspace_bytes(Po))
+        self._ck(self.lib.uda_stem_wgrad(x.data_ptr(), N, H, W, g, ldg, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         self._stream()))
+
+    # ------------------------------------------------------------------ batch norm
+    def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, invstd):
+        Cc = gamma.numel()
+        for t in (gamma, beta, rmean, rvar, scale, shift, mean, invstd):
+            assert t.is_contiguous() and t.numel() == Cc
+        assert stats.dtype == torch.float64 and stats.is_contiguous()
+        self._ck(self.lib.uda_bn_finalize(stats.data_ptr(), Cc, float(count), gamma.data_ptr(), beta.data_ptr(),
+                                          rmean.data_ptr(), rvar.data_ptr(), momentum, eps, scale.data_ptr(),
+                                          shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), self._stream()))
+
+    def bn_eval_coeffs(self, gamma, beta, rmean, rvar, eps, scale, shift):
+        Cc = gamma.numel()
+        for t in (gamma, beta, rmean, rvar, scale, shift):
+            assert t.is_contiguous() and t.numel() == Cc
+        self._ck(self.lib.uda_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), Cc,
+                                             eps, scale.data_ptr(), shift.data_ptr(), self._stream()))
+
+    def bn_apply(self, src: Act, out, residual=None):
+        s = self._src(src)
+        assert out.shape == src.x.shape and src.C % 4 == 0
+        o, ldo = _mat(out, "out")
+        r, ldr = (None, 0) if residual is None else _mat(residual, "residual")
+        self._ck(self.lib.uda_bn_apply(C.byref(s), r, ldr, o, ldo, self._stream()))
+
+    def colstats(self, x, stats):
+        self._dev(x)
+        p, ld = _mat(x, "x")
+        nq, Cc = stats.shape
+        assert Cc == x.shape[1] and stats.dtype == torch.float64 and stats.is_contiguous()
+        ws = self._ws(x, self.lib.uda_reduce_workspace_bytes(x.shape[0], Cc, nq))
+        self._ck(self.lib.uda_colstats(p, ld, x.shape[0], Cc, nq, stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       self._stream()))
+
+    def colsum(self, x, out):
+        st = torch.zeros(1, x.shape[1], dtype=torch.float64, device=x.device)
+        self.colstats(x, st)
+        out.copy_(st[0])
+
+    def bnbwd_reduce(self, dU, y: Act, sums):
+        s = self._src(y)
+        assert dU.shape == y.x.shape and sums.dtype == torch.float64 and tuple(sums.shape) == (3, y.C)
+        d, ldu = _mat(dU, "dU")
+        ws = self._ws(dU, self.lib.uda_reduce_workspace_bytes(y.P, y.C, 3))
+        self._ck(self.lib.uda_bnbwd_reduce(d, ldu, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
+                                           sums.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+
+    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
+        self._ck(self.lib.uda_bnbwd_finalize(sums.data_ptr(), y.C, float(y.bn.count), int(y.bn.q1_border), y.act,
+                                             y.shift.data_ptr(), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
+                                             c1.data_ptr(), c2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                             self._stream()))
+
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None):
+        s = self._src(y)
+        assert dU.shape == y.x.shape == out.shape
+        d, ldu = _mat(dU, "dU")
+        o, ldo = _mat(out, "out")
+        ad, lda = (None, 0) if addend is None else _mat(addend, "addend")
+        self._ck(self.lib.uda_bnbwd_apply(d, ldu, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
+                                          c1.data_ptr(), c2.data_ptr(), ad, lda, o, ldo, self._stream()))
+
+    # ------------------------------------------------------------------ resampling / pooling
+    def upsample_fwd(self, x, N, h, w, out, H, W):
+        self._dev(x)
+        p, ld = _mat(x, "x")
+        o, ldo = _mat(out, "out")
+        assert x.shape[0] == N * h * w and out.shape == (N * H * W, x.shape[1])
+        self._ck(self.lib.uda_upsample_fwd(p, ld, N, h, w, x.shape[1], o, ldo, H, W, self._stream()))
+
+    def upsample_bwd(self, dout, N, H, W, dx, h, w):
+        p, ld = _mat(dout, "dout")
+        o, ldo = _mat(dx, "dx")
+        assert dout.shape[0] == N * H * W and dx.shape == (N * h * w, dout.shape[1])
+        self._ck(self.lib.uda_upsample_bwd(p, ld, N, H, W, dout.shape[1], o, ldo, h, w, self._stream()))
+
+    def head_upsample_fwd(self, x, N, h, w, out):
+        self._dev(x)
+        p, ld = _mat(x, "x")
+        Cc = x.shape[1]
+        assert out.is_contiguous() and out.shape[0] == N and out.shape[1] == Cc and x.shape[0] == N * h * w
+        self._ck(self.lib.uda_head_upsample_fwd(p, ld, N, h, w, Cc, out.data_ptr(), out.shape[2], out.shape[3],
+                                                self._stream()))
+
+    def head_upsample_bwd(self, dout, dx, N, h, w, accumulate=False):
+        self._dev(dout)
+        p, ld = _mat(dx, "dx")
+        assert dout.is_contiguous() and dout.shape[0] == N and dout.shape[1] == dx.shape[1] and dx.shape[0] == N * h * w
+        self._ck(self.lib.uda_head_upsample_bwd(dout.data_ptr(), N, dout.shape[1], dout.shape[2], dout.shape[3], p, ld,
+                                                h, w, int(accumulate), self._stream()))
+
+    def gap_fwd(self, x, N, out, scale):
+        self._dev(x)
+        p, ld = _mat(x, "x")
+        o, ldo = _mat(out, "out")
+        assert x.shape[0] % N == 0 and out.shape == (N, x.shape[1])
+        self._ck(self.lib.uda_gap_fwd(p, ld, N, x.shape[0] // N, x.shape[1], scale, o, ldo, self._stream()))
+
+    def broadcast_rows(self, g, N, out, scale, addend=None):
+        self._dev(g)
+        p, ld = _mat(g, "g")
+        o, ldo = _mat(out, "out")
+        assert g.shape == (N, out.shape[1]) and out.shape[0] % N == 0
+        ad, lda = (None, 0) if addend is None else _mat(addend, "addend")
+        self._ck(self.lib.uda_broadcast_rows(p, ld, N, out.shape[0] // N, out.shape[1], scale, ad, lda, o, ldo,
+                                             self._stream()))
+
+    def dropout_mask(self, mask, p, seed, offset):
+        self._dev(mask)
+        assert mask.dtype == torch.uint8 and mask.stride(1) == 1
+        self._ck(self.lib.uda_dropout_mask(mask.data_ptr(), mask.stride(0), mask.shape[0], mask.shape[1], p,
+                                           int(seed), int(offset), self._stream()))

@@ -155,6 +155,43 @@ int uda_broadcast_rows(const float* g, int64_t ldg, int N, int HW, int C, float 
 int uda_dropout_mask(uint8_t* mask, int64_t ldm, int64_t P, int C, float p, uint64_t seed,
                      uint64_t offset, void* stream);
 
+/* ---- segmentation loss: BCELoss(sigmoid(o), map) + MSELoss(sigmoid(b), boundary), both 'mean'
+ * (Trainer_prototype_full.py:18-19,292-294; Trainer_baseline.py:206-208; log clamp -100).
+ * loss3 (device float[3]) = (total, bce, mse); workspace2 = device double[2].
+ * bwd: d_o / d_b = gradient of the total times the device scalar *gscale. */
+int uda_seg_loss_fwd(const float* o, const float* map, int64_t n_o, const float* b, const float* boundary,
+                     int64_t n_b, float* loss3, double* workspace2, void* stream);
+int uda_seg_loss_bwd(const float* o, const float* map, int64_t n_o, const float* b, const float* boundary,
+                     int64_t n_b, const float* gscale, float* d_o, float* d_b, void* stream);
+/* counts[c][3] = (intersection, predicted, ground-truth) pixels for sigmoid(logit) > thr
+ * (utils/metrics.py:118-132,149-168: Dice, pixel accuracy and IoU follow from them) */
+int uda_seg_counts(const float* logits, const float* target, int B, int C, int64_t HW, float thr,
+                   uint64_t* counts, void* stream);
+
+/* ---- category prototypes (utils/Utils.py:108-131, 159-225) */
+/* preds [T][n] logits -> unbiased std over T of sigmoid(x/2), mean over T of sigmoid(x)  (T = 8) */
+int uda_mc_stats(const float* preds, int T, int64_t n, float* std_map, float* mean_map, void* stream);
+/* wts [P][4] for the classes (cup obj, disc obj, cup bck, disc bck);
+ * mode 0: from a [B,2,H,W] map, nearest-resized to h x w;  mode 1: from sigmoid of [P,2] logits;
+ * mode 2: retrified pseudo labels (sigmoid>0.75) x (bilinear(std)<0.04) x bilinear(mean) */
+int uda_proto_weights(int mode, int B, int h, int w, int H, int W, const float* map, const float* logits,
+                      int64_t ldl, const float* std_map, const float* mean_map, float* wts, float* mask0,
+                      float* mask1, void* stream);
+uint64_t uda_proto_workspace_bytes(int64_t P, int C);
+/* sums (double[4][C+1], ADDED into): weighted channel sums, then the weight total, per class */
+int uda_proto_reduce(const float* feat, int64_t ldf, int64_t P, int C, const float* wts, double* sums,
+                     float* workspace, uint64_t workspace_bytes, void* stream);
+int uda_proto_finalize(const double* sums, int C, float* centroids /* [4][C] */, void* stream);
+/* adjoint of centroid = sum/count: d_feat[P,C] (optional, optionally accumulated) and d_w[P,4] (optional) */
+int uda_proto_bwd(const float* feat, int64_t ldf, int64_t P, int C, const float* wts, const double* sums,
+                  const float* dC, float* coef_ws /* float[4][C+1] */, float* d_feat, int64_t ldd,
+                  int accumulate, float* d_w, void* stream);
+
+/* ---- torch.optim.Adam update (no weight decay / amsgrad) over one flat fp32 buffer
+ * (train_use_fix_initial.py:210-214) */
+int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,6 +222,10 @@ def case_bn(P, C, q1=False, mask=False, training=True, seed=5):
             K.bn_eval_coeffs(gamma.to(dev), beta.to(dev), rmh, rvh, 1e-5, ch[0], ch[1])
             cr[2:], ch[2:] = 0.0, 0.0
             errs.append(rel(ch[:2], cr[:2]))
+        # keep pre-activations away from the ReLU/ReLU6 kinks: there the gate legitimately depends
+        # on fma-vs-(mul,add) rounding, which is not what this case tests
+        a0 = x * cr[0] + cr[1]
+        x[(a0.abs() < 1e-4) | ((a0 - 6).abs() < 1e-4)] += 0.01
         if C % 4 == 0:
             m = None
             if mask:
@@ -411,4 +415,120 @@ CASES = [
     ("gap C=256 HW=16", case_gap(4, 16, 256)),
     ("dropout p=.5", case_dropout(4096, 256, 0.5)),
     ("dropout p=.1 C=305", case_dropout(4096, 305, 0.1)),
+]
+
+
+# ------------------------------------------------------------------------------------- losses / prototypes
+def case_seg_loss(B, S, seed=10):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        o = 3 * torch.randn(B, 2, S, S, generator=g)
+        o[0, 0, 0, :8] = torch.tensor([40., -40., 110., -110., 17., -17., 90., -90.])    # saturating logits (log clamp)
+        b = 2 * torch.randn(B, 1, S, S, generator=g)
+        tm = (torch.rand(B, 2, S, S, generator=g) > 0.5).float()
+        tb = torch.rand(B, 1, S, S, generator=g)
+        l_r = SPEC.seg_loss_fwd(o, tm, b, tb)
+        l_h = K.seg_loss_fwd(o.to(dev), tm.to(dev), b.to(dev), tb.to(dev))
+        gs = torch.tensor([0.37])
+        do_r, db_r = SPEC.seg_loss_bwd(o, tm, b, tb, gs)
+        do_h, db_h = K.seg_loss_bwd(o.to(dev), tm.to(dev), b.to(dev), tb.to(dev), gs.to(dev))
+        return max(rel(l_h, l_r), rel(do_h, do_r), rel(db_h, db_r)), 2e-5
+    return run
+
+
+def case_seg_counts(B, S, seed=11):
+    def run(dev):
+        g = gen(seed)
+        lg = 2 * torch.randn(B, 2, S, S, generator=g) + 1.0
+        tg = (torch.rand(B, 2, S, S, generator=g) > 0.6).float()
+        c_r = SPEC.seg_counts(lg, tg, 0.75)
+        c_h = hip().seg_counts(lg.to(dev), tg.to(dev), 0.75)
+        # a logit within one ulp of the threshold may flip: allow a handful of pixels
+        return float((c_h.cpu() - c_r).abs().max()) / 4.0, 1.0
+    return run
+
+
+def case_proto(B, h, C, mode, seed=12):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        P = B * h * h
+        feat = padded(P, C, g)
+        H = 4 * h
+        errs = []
+        if mode == 0:
+            mp = (torch.rand(B, 2, H, H, generator=g) > 0.6).float()
+            w_r, _, _ = SPEC.proto_weights(0, B, h, h, map_=mp)
+            w_h, _, _ = K.proto_weights(0, B, h, h, map_=mp.to(dev))
+        elif mode == 1:
+            lg = padded(P, 2, g, scale=2.0)
+            w_r, _, _ = SPEC.proto_weights(1, B, h, h, logits=lg)
+            w_h, _, _ = K.proto_weights(1, B, h, h, logits=to_dev(lg, dev))
+        else:
+            T = 8
+            base = torch.nn.functional.avg_pool2d(2.0 * torch.randn(B, 2, H, H, generator=g), 9, 1, 4) * 6.0
+            preds = base.repeat(T, 1, 1, 1) + 0.35 * torch.randn(T * B, 2, H, H, generator=g) * \
+                (torch.rand(1, 2, H, H, generator=g) > 0.5).float()
+            sd_r, mn_r = SPEC.mc_stats(preds, T)
+            sd_h, mn_h = K.mc_stats(preds.to(dev), T)
+            errs += [rel(sd_h, sd_r), rel(mn_h, mn_r)]
+            lgn = torch.nn.functional.interpolate(base, size=(h, h), mode="bilinear", align_corners=True)
+            lg = padded(P, 2, g)
+            lg.copy_(lgn.permute(0, 2, 3, 1).reshape(P, 2))
+            w_r, m0_r, m1_r = SPEC.proto_weights(2, B, h, h, logits=lg, std_map=sd_r, mean_map=mn_r)
+            # feed the HIP weights kernel the reference std/mean so that threshold flips cannot differ
+            w_h, m0_h, m1_h = K.proto_weights(2, B, h, h, logits=to_dev(lg, dev), std_map=sd_r.to(dev), mean_map=mn_r.to(dev))
+            flips = int((m0_h.cpu() != m0_r).sum() + (m1_h.cpu() != m1_r).sum())
+            assert flips <= 4, "reliability mask differs on %d pixels" % flips
+            if flips:
+                w_h = w_r.to(dev)
+            assert 0.05 < float(m0_r.mean()) / 2 < 0.999, "degenerate mask in the test input"
+        errs.append(rel(w_h, w_r))
+        s_r = torch.zeros(4, C + 1, dtype=torch.float64)
+        SPEC.proto_reduce(feat, w_r, s_r)
+        s_h = torch.zeros(4, C + 1, dtype=torch.float64, device=dev)
+        fh, wh = to_dev(feat, dev), w_r.to(dev)
+        K.proto_reduce(fh, wh, s_h)
+        errs += [rel(s_h, s_r), rel(K.proto_finalize(s_h), SPEC.proto_finalize(s_r))]
+        dC = torch.randn(4, C, generator=g)
+        base = padded(P, C, g)
+        df_r = base.clone()
+        dw_r = SPEC.proto_bwd(feat, w_r, s_r, dC, df_r, True, True)
+        df_h = to_dev(base, dev)
+        dw_h = K.proto_bwd(fh, wh, s_h, dC.to(dev), df_h, True, True)
+        errs += [rel(df_h, df_r), rel(dw_h, dw_r)]
+        DETAIL.clear()
+        DETAIL.update({"errs": ["%.1e" % e for e in errs]})
+        return max(errs), 3e-5
+    return run
+
+
+def case_adam(n, seed=13):
+    def run(dev):
+        g = gen(seed)
+        p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        m, v = 0.1 * torch.randn(n, generator=g), torch.rand(n, generator=g) * 0.01
+        ph, mh, vh = p.to(dev), m.to(dev), v.to(dev)
+        for step in (1, 2, 7):
+            SPEC.adam_step(p, gr, m, v, 1e-3, 0.9, 0.99, 1e-8, step)
+            hip().adam_step(ph, gr.to(dev), mh, vh, 1e-3, 0.9, 0.99, 1e-8, step)
+        ref = torch.nn.Parameter(torch.randn(n, generator=gen(seed)))
+        return max(rel(ph, p), rel(mh, m), rel(vh, v)), 1e-5
+    return run
+
+
+CASES += [
+    # wide warp-specialised tiles (BN = 256 needs >= 512 workgroups: P >= 65536)
+    ("conv3x3 16->256 P=65536 (BN=256 tiles) relu mask", case_conv(4, 128, 128, 16, 256, 3, 1, mask=True)),
+    ("conv1x1 64->200 P=65536 (BN=256 tiles) bias addend", case_conv(4, 128, 128, 64, 200, 1, 1, bias=True, addend=True)),
+    ("dgrad3x3 304<-32 P=65536 accumulate", case_dgrad(4, 128, 128, 304, 32, 3, 1, accumulate=True)),
+    ("wgrad3x3 16->256 P=65536 mask", case_wgrad(4, 128, 128, 16, 256, 3, 1, mask=True)),
+    ("seg loss 2x64", case_seg_loss(2, 64)),
+    ("seg counts 3x96", case_seg_counts(3, 96)),
+    ("proto hard C=305 h=32", case_proto(2, 32, 305, 0)),
+    ("proto soft C=305 h=16", case_proto(2, 16, 305, 1)),
+    ("proto retrify C=305 h=32", case_proto(1, 32, 305, 2)),
+    ("proto hard C=64 h=8", case_proto(3, 8, 64, 0)),
+    ("adam 100003", case_adam(100003)),
 ]

@@ -294,3 +294,74 @@ class SpecKernels:
         the device); parity tests inject masks instead of comparing streams."""
         g = torch.Generator(device="cpu").manual_seed(int(seed) * 1000003 + int(offset))
         mask.copy_((torch.rand(mask.shape, generator=g) >= p).to(torch.uint8).to(mask.device))
+
+    # ------------------------------------------------------------------ losses / metrics
+    def seg_loss_fwd(self, o, tmap, b, tbd):
+        bce = F.binary_cross_entropy(torch.sigmoid(o), tmap)
+        mse = F.mse_loss(torch.sigmoid(b), tbd)
+        return torch.stack([bce + mse, bce, mse])
+
+    def seg_loss_bwd(self, o, tmap, b, tbd, gscale):
+        o2, b2 = o.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+        (F.binary_cross_entropy(torch.sigmoid(o2), tmap) + F.mse_loss(torch.sigmoid(b2), tbd)).backward()
+        return o2.grad * gscale, b2.grad * gscale
+
+    def seg_counts(self, logits, target, thr):
+        pr = torch.sigmoid(logits) > thr
+        gt = target != 0
+        return torch.stack([(pr & gt).sum((0, 2, 3)), pr.sum((0, 2, 3)), gt.sum((0, 2, 3))], 1).to(torch.int64)
+
+    # ------------------------------------------------------------------ prototypes
+    def mc_stats(self, preds, T):
+        p = preds.reshape((T, preds.shape[0] // T) + tuple(preds.shape[1:]))
+        return torch.std(torch.sigmoid(p / 2.0), dim=0), torch.mean(torch.sigmoid(p), dim=0)
+
+    def proto_weights(self, mode, B, h, w, map_=None, logits=None, std_map=None, mean_map=None):
+        m0 = m1 = None
+        if mode == 0:
+            m = F.interpolate(map_, size=(h, w), mode="nearest")
+            a, b = m[:, 0], m[:, 1]
+            ws = (a, b, 1 - a, 1 - b)
+        else:
+            p = torch.sigmoid(logits).reshape(B, h, w, 2)
+            if mode == 1:
+                ws = (p[..., 0], p[..., 1], 1 - p[..., 0], 1 - p[..., 1])
+            else:
+                pl = (p > 0.75).float()
+                sd = F.interpolate(std_map, size=(h, w), mode="bilinear", align_corners=True)
+                q = F.interpolate(mean_map, size=(h, w), mode="bilinear", align_corners=True)
+                mk = (sd < 0.04).float()
+                ws = (mk[:, 0] * pl[..., 0] * q[:, 0], mk[:, 1] * pl[..., 1] * q[:, 1],
+                      mk[:, 0] * (1 - pl[..., 0]) * (1 - q[:, 0]), mk[:, 1] * (1 - pl[..., 1]) * (1 - q[:, 1]))
+                m0, m1 = (2 * mk[:, 0]).reshape(-1), (2 * mk[:, 1]).reshape(-1)
+        return torch.stack([t.reshape(-1) for t in ws], 1).contiguous(), m0, m1
+
+    def proto_reduce(self, feat, wts, sums):
+        Cc = feat.shape[1]
+        sums[:, :Cc] += wts.double().t() @ feat.double()
+        sums[:, Cc] += wts.double().sum(0)
+
+    def proto_finalize(self, sums):
+        Cc = sums.shape[1] - 1
+        return (sums[:, :Cc] / sums[:, Cc:]).float()
+
+    def proto_bwd(self, feat, wts, sums, dC, d_feat=None, accumulate=False, want_dw=False):
+        Cc = feat.shape[1]
+        cnt = sums[:, Cc:]
+        coef = dC.double() / cnt                                           # [4, C]
+        extra = -(dC.double() * sums[:, :Cc]).sum(1) / cnt[:, 0] ** 2      # [4]
+        if d_feat is not None:
+            g = (wts.double() @ coef).float()
+            if accumulate:
+                d_feat.add_(g)
+            else:
+                d_feat.copy_(g)
+        if want_dw:
+            return (feat.double() @ coef.t() + extra).float()
+        return None
+
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+        exp_avg.mul_(beta1).add_(grads, alpha=1 - beta1)
+        exp_avg_sq.mul_(beta2).addcmul_(grads, grads, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        params.addcdiv_(exp_avg, exp_avg_sq.sqrt() / (bc2 ** 0.5) + eps, value=-lr / bc1)

@@ -1,0 +1,101 @@
+"""not-gpu: host logic of the product Trainer classes (loop order, LR rule, log.csv / checkpoint
+format, validation averaging) driven with the oracle model + oracle ops, checked against the rows
+the REFERENCE's own Trainer loops wrote (tests/golden/trainer_*.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from make_golden_inputs import synth_loader
+from oracle import deeplab_ref, step_ref
+from oracle_ops import OracleOps
+from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
+from uda_clr_amd.networks.deeplabv3 import DeepLab
+from uda_clr_amd.train_process import Trainer_baseline, Trainer_prototype_full
+
+
+def _oracle_model():
+    torch.manual_seed(1337)
+    return deeplab_ref.OracleDeepLab(DeepLab(num_classes=2, backbone="mobilenet", output_stride=16).state_dict())
+
+
+def _rows(path):
+    with open(path) as f:
+        return [l.split(",") for l in f.read().strip().split("\n")[1:]]
+
+
+def test_trainer_baseline_reproduces_reference_rows(golden_dir, tmp_path):
+    z = json.load(open(os.path.join(golden_dir, "trainer_baseline.json")))
+    m = _oracle_model()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
+    loaderS = synth_loader(z["n_batches_S"], z["B"], z["S"], z["loaderS_seed"])
+    loaderV = synth_loader(z["n_batches_V"], z["B"], z["S"], z["loaderV_seed"])
+    torch.manual_seed(z["torch_seed"])
+    tr = Trainer_baseline.Trainer(cuda=False, model_gen=m, optimizer_gen=opt, lr_gen=1e-3, lr_decrease_rate=0.1,
+                                  val_loader=loaderV, domain_loaderS=loaderS, domain_loaderT=loaderS, out=str(tmp_path),
+                                  max_epoch=z["epochs"], stop_epoch=z["epochs"], interval_validate=1, batch_size=z["B"],
+                                  warmup_epoch=-1)
+    tr.ops = OracleOps()
+    tr.epoch = 0
+    tr.iteration = 0
+    tr.train()
+    rows = _rows(tmp_path / "log.csv")
+    train = [float(r[2]) for r in rows if r[2] != ""]
+    np.testing.assert_allclose(train, z["train_loss"], rtol=2e-4)
+    val = [r for r in rows if r[2] == ""]
+    assert len(val) == len(z["val"])
+    for r, ref in zip(val, z["val"]):
+        txt = ",".join(r)
+        got = [float(v) for v in txt[txt.index("(") + 1: txt.index(")")].split(",")]
+        np.testing.assert_allclose(got, ref, rtol=2e-4)
+    # header + checkpoint format of the reference (Trainer_baseline.py:53-63, validate())
+    assert open(tmp_path / "log.csv").readline().strip().split(",")[:3] == ["epoch", "iteration", "train/loss_seg"]
+    ck = [f for f in os.listdir(tmp_path) if f.startswith("checkpoint_")]
+    assert ck, "best-Dice checkpoint expected"
+    sd = torch.load(tmp_path / ck[0], weights_only=False)
+    assert {"epoch", "iteration", "arch", "optim_state_dict", "model_state_dict", "learning_rate_gen", "best_mean_dice"} <= set(sd)
+
+
+def test_trainer_prototype_full_reproduces_reference_rows(golden_dir, tmp_path):
+    """Called with the SHIPPED caller's keyword set (train_use_fix_initial.py:276-304)."""
+    z = json.load(open(os.path.join(golden_dir, "trainer_proto.json")))
+    m = _oracle_model()
+    torch.manual_seed(z["dis_seed"])
+    d1, d2 = BoundaryDiscriminator(), UncertaintyDiscriminator()
+    og, od, od2 = step_ref.make_optimizers(m, d1, d2)
+    loaderS = synth_loader(z["n_batches"], z["B"], z["S"], z["loaderS_seed"])
+    loaderT = synth_loader(z["n_batches"], z["B"], z["S"], z["loaderT_seed"])
+    torch.manual_seed(z["torch_seed"])
+    tr = Trainer_prototype_full.Trainer(
+        cuda=False, model_gen=m, model_geninitial_pesudolabel=None, model_dis=d1, model_uncertainty_dis=d2,
+        optimizer_gen=og, optimizer_dis=od, optimizer_uncertainty_dis=od2, lr_gen=1e-3, lr_dis=2.5e-5, lr_decrease_rate=0.1,
+        val_loader=loaderT, domain_loaderS=loaderS, domain_loaderT=loaderT, out=str(tmp_path), max_epoch=1, stop_epoch=1,
+        interval_validate=100, batch_size=z["B"], warmup_epoch=-1, target_name="RIM-ONE_r3", use_fix_initial=False,
+        use_pid=True, use_TN=False, retrify_pesudo=True, global_pro_weight=0.9, pro_weight=0.1)
+    tr.ops = OracleOps()
+    tr.epoch = 0
+    tr.iteration = 0
+    tr.train()
+    rows = [[float(v) for v in r[2:8]] for r in _rows(tmp_path / "log.csv") if r[2] != ""]
+    np.testing.assert_allclose(rows, z["rows"], rtol=5e-4)
+
+
+def test_union_signature_and_warmup_phase(tmp_path):
+    """The shipped class signature (use_global positional-by-name) also works, and the warm-up phase
+    (use_pid, epoch <= warmup_epoch), which crashes in the shipped file, trains seg + adv."""
+    m = _oracle_model()
+    d1, d2 = BoundaryDiscriminator(), UncertaintyDiscriminator()
+    og, od, od2 = step_ref.make_optimizers(m, d1, d2)
+    loader = synth_loader(1, 2, 64, 40)
+    tr = Trainer_prototype_full.Trainer(False, m, d1, d2, og, od, od2, loader, loader, loader, str(tmp_path), 1,
+                                        use_global=True, use_pid=True, retrify_pesudo=True, global_pro_weight=0.9,
+                                        pro_weight=0.1, stop_epoch=1, warmup_epoch=25)
+    tr.ops = OracleOps()
+    m.train(); d1.train(); d2.train()
+    vals = tr.train_step(loader[0], loader[0])
+    assert len(vals) == 4 and all(np.isfinite(vals))
+    with pytest.raises(NotImplementedError):
+        Trainer_prototype_full.Trainer(False, m, d1, d2, og, od, od2, loader, loader, loader, str(tmp_path), 1,
+                                       use_global=False, use_pid=True)

@@ -1,0 +1,34 @@
+// Kernel-argument blocks shared by igemm_conv.hip (single-role kernels, narrow tiles) and
+// igemm_ws.hip (warp-specialised kernels, wide tiles).
+#pragma once
+#include "common.h"
+
+struct ConvKArgs {
+    uda_src_t src;
+    const float* w;
+    int Cout, ksize, dil, Kc, Ktot;
+    const float* bias;
+    const float* addend;
+    int64_t ld_add;
+    float* y;
+    int64_t ldy;
+    float* part;   // [nMt][2][Cout] or null
+    int nMt, nNt;
+    int debug;     // diagnostics only (UDA_WS_DEBUG): bit0 skip MFMAs, bit1 skip loader work
+};
+
+struct WgradKArgs {
+    uda_src_t src;
+    const float* dy;
+    int64_t lddy;
+    int Cout, ksize, dil, Kc, Jtot;
+    float* slab;      // [S][Cout][Jtot]
+    int nCot, nJt, chunks_per_split, nchunks;
+};
+
+#define IG_BK 32
+#define IG_LD 36
+#define WG_BKP 32
+
+int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st);          // 128 x {128,256} tiles
+int launch_wgrad_ws(WgradKArgs& k, int S, hipStream_t st);            // 128 x 128 tiles

@@ -18,24 +18,10 @@
 //   Tiles are ordered n-fastest and XCD-chunked (uda_xcd_remap) so the two N tiles of a pixel
 //   tile and spatially adjacent pixel tiles share one XCD's L2.
 #include "common.h"
+#include "igemm_args.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct ConvKArgs {
-    uda_src_t src;
-    const float* w;
-    int Cout, ksize, dil, Kc, Ktot;
-    const float* bias;
-    const float* addend;
-    int64_t ld_add;
-    float* y;
-    int64_t ldy;
-    float* part;   // [nMt][2][Cout] or null
-    int nMt, nNt;
-};
-
-#define IG_BK 32
-#define IG_LD 36
 
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
@@ -301,6 +287,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.y = a->y;
     k.ldy = a->ldy;
     k.part = nullptr;
+    k.debug = 0;
     if (a->stats) {
         UDA_REQUIRE(a->workspace && a->workspace_bytes >= uda_conv_workspace_bytes(P, a->Cout),
                     "uda_conv_fwd: workspace too small for the BN statistics partials");
@@ -310,7 +297,8 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
-    else e = launch_conv<2, 2, 2, 2>(k, P, st);
+    else if (k.Ktot <= 192) e = launch_conv<2, 2, 2, 2>(k, P, st);     // short K: HBM-bound, single-role tiles
+    else e = launch_conv_ws(k, P, st);
     if (e) return e;
     if (a->stats) return uda_reduce_partials(k.part, k.nMt, 2 * a->Cout, a->stats, st);
     return 0;
@@ -321,16 +309,6 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
 // Operands are staged [pixel][row] (row fastest) so the MFMA operand reads are plain ds_read_b32
 // of 32 consecutive dwords.  The pixel range is split over blockIdx.y; every split writes its
 // own fp32 slab and a second kernel sums the slabs (bitwise reproducible, no float atomics).
-struct WgradKArgs {
-    uda_src_t src;
-    const float* dy;
-    int64_t lddy;
-    int Cout, ksize, dil, Kc, Jtot;
-    float* slab;      // [S][Cout][Jtot]
-    int nCot, nJt, chunks_per_split, nchunks;
-};
-
-#define WG_BKP 32
 
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
@@ -544,7 +522,7 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     k.chunks_per_split = p.cps;
     k.nchunks = p.nchunks;
     dim3 grid(p.nCot * p.nJt, p.S);
-    if (p.bm == 128 && p.bn == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, k);
+    if (p.bm == 128 && p.bn == 128) { if (int e = launch_wgrad_ws(k, p.S, st)) return e; }
     else if (p.bm == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, k);
     else if (p.bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 4, 1>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 1, 4>), grid, dim3(256), 0, st, k);

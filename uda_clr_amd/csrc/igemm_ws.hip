@@ -1,0 +1,526 @@
+// Warp-specialised FP32-MFMA implicit-GEMM kernels for the wide (MFMA-bound) convolutions on gfx950.
+//
+// Measured on the single-role kernel (igemm_conv.hip, rocprofv3 PMC, decoder 3x3 at B=16): 6.5 VALU
+// instructions per MFMA (address arithmetic + BN/ReLU/dropout prologue + LDS staging) and a
+// matrix pipe busy 65 % of the time: with one role per wave the staging phases of the two co-resident
+// waves of a SIMD leave the pipe idle.  Here a 512-thread workgroup puts TWO waves on every SIMD
+// with fixed roles:
+//     waves 0-3  "math"   : only ds_read_b128 operand fragments + v_mfma_f32_32x32x2_f32
+//     waves 4-7  "loader" : global -> registers -> (prologue) -> LDS for the NEXT K-chunk
+// on a double-buffered LDS tile pair with ONE barrier per chunk, so every SIMD always has a wave
+// whose next instruction is an MFMA while its partner does the vector/memory work (the
+// producer/consumer split of the guide's loader-ring engines, with barriers instead of flags since
+// both roles live in one workgroup).  Loader waves are the later-dispatched half, i.e. they lose
+// issue arbitration to the math waves (MI355X_MICROARCH.md "Two waves per SIMD").
+//
+// Tile: BM = 128 pixels x BN = 64*TN couts (TN = 2 -> 128, TN = 4 -> 256: whole Cout = 256 of the
+// decoder / ASPP convs in one tile, so the activation tile is staged once), BK = 32.
+#include "common.h"
+#include <stdlib.h>
+#include "igemm_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// XF: 0 = raw operand, 1 = BN affine + activation, 2 = same + dropout keep-mask
+template <int KS, int XF, int TN>
+__global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
+    constexpr int BM = 128, BN = 64 * TN, TM = 2;
+    constexpr int B_IT = BN / 32;
+    constexpr int TILE = (BM + BN) * IG_LD;        // floats per buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= 4;     // provably wave-uniform
+    const int lid = uda_xcd_remap(blockIdx.x, a.nMt * a.nNt);
+    const int mt = lid / a.nNt, nt = lid % a.nNt;
+    const int H = a.src.H, W = a.src.W, C = a.src.C;
+    const int64_t P = (int64_t)a.src.N * H * W;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const int nchunks = (a.Ktot + IG_BK - 1) / IG_BK;
+
+    // ------------------------------------------------------------------ loader state
+    // All per-row quantities are precomputed once (32-bit element offsets, a 9-bit tap-validity
+    // mask per pixel row); a K-chunk then costs ~6 VALU per operand row instead of a 64-bit
+    // multiply + four compares.  (PMC on the first version: loader waves, not the MFMA pipe, set the
+    // chunk time: 11.4k-13.6k cycles against 8.2k cycles of MFMA work.)
+    const int lt = tid & 255, lrow = lt >> 3, kv = (lt & 7) * 4;
+    int rowoff[4], rowoffm[4], boff[B_IT];
+    unsigned vmask[4];
+    float4 areg[4], breg[B_IT];
+    uint32_t amask[4];
+    unsigned aok = 0;
+    Xf4 xf;
+    int st_ci = 0;               // channel of the staged registers' first element
+    int t_cur = 0, ci_cur = kv;  // (tap, channel) of the NEXT chunk to issue
+    if (loader) {
+        const int ldx = (int)a.src.ldx, ldm = (int)a.src.ldm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t p = m0 + lrow + 32 * i;
+            const bool ok = p < P;
+            const int q = ok ? (int)p : 0;
+            const int pw = q % W, ph = (q / W) % H;
+            rowoff[i] = q * ldx;
+            rowoffm[i] = q * ldm;
+            unsigned vm = 0;
+            if (ok) {
+                if (KS == 3) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int hh = ph + (t / 3 - 1) * a.dil, ww = pw + (t % 3 - 1) * a.dil;
+                        vm |= (hh >= 0 && hh < H && ww >= 0 && ww < W ? 1u : 0u) << t;
+                    }
+                } else {
+                    vm = 1u;
+                }
+            }
+            vmask[i] = vm;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + lrow + 32 * i;
+            boff[i] = n < a.Cout ? n * a.Ktot : -1;
+        }
+        if (KS == 3) {
+            t_cur = kv / a.Kc;
+            ci_cur = kv - t_cur * a.Kc;
+        }
+    }
+
+    auto issue = [&]() {       // loads of the chunk at (t_cur, ci_cur); then advance by BK
+        const int t = t_cur, ci = ci_cur;
+        const bool kval = KS == 3 ? (t < 9) : (ci < a.Kc);
+        st_ci = ci;
+        int tapoff = 0;
+        if (KS == 3) tapoff = ((t / 3 - 1) * W + (t % 3 - 1)) * a.dil;
+        if (XF >= 1) uda_load_xf4(xf, a.src.scale, a.src.shift, ci, kval ? C : 0);
+        const int xoff = tapoff * (int)a.src.ldx + ci;
+        const int moff = tapoff * (int)a.src.ldm + ci;
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = kval && ((vmask[i] >> (KS == 3 ? t : 0)) & 1u);
+            areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            amask[i] = 0;
+            if (ok) {
+                areg[i] = uda_ld4(a.src.x + (rowoff[i] + xoff));
+                if (XF == 2) amask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + (rowoffm[i] + moff));
+                aok |= 1u << i;
+            }
+        }
+        const int k0 = KS == 3 ? t * a.Kc + ci : ci;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            breg[i] = (kval && boff[i] >= 0) ? uda_ld4(a.w + (boff[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ci_cur += IG_BK;
+        if (KS == 3) {
+            while (ci_cur >= a.Kc) {
+                ci_cur -= a.Kc;
+                ++t_cur;
+            }
+        }
+    };
+
+    auto stage = [&](float* buf) {
+        float* As = buf;
+        float* Bs = buf + BM * IG_LD;
+        const int act = a.src.act;
+        const float ms = a.src.mask_scale;
+        const bool ctail = (C & 3) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            const bool ok = (aok >> i) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j];
+                if (XF >= 1) {
+                    // multiplier: 0 outside the image, keep-mask * 1/(1-p) inside (v_cvt_f32_ubyteN)
+                    float mul = ok ? 1.f : 0.f;
+                    if (XF == 2) mul = (float)((amask[i] >> (8 * j)) & 0xffu) * ms;   // amask = 0 when !ok
+                    u = uda_act(u * xf.sc[j] + xf.sh[j], act) * mul;
+                }
+                if (ctail && (st_ci + j) >= C) u = 0.f;
+                v[j] = u;
+            }
+            uda_st4(&As[(lrow + 32 * i) * IG_LD + kv], make_float4(v[0], v[1], v[2], v[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) uda_st4(&Bs[(lrow + 32 * i) * IG_LD + kv], breg[i]);
+    };
+
+    // ------------------------------------------------------------------ math state
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
+    const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TN) + (lane & 31);
+    const int koff = 4 * (lane >> 5);
+
+    // ------------------------------------------------------------------ pipeline
+    // The role branch is OUTERMOST (wave-uniform, scalar branch) so the register allocation is the
+    // maximum of the two roles' live sets, not their sum; both roles execute the same number of
+    // workgroup barriers.
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    if (loader) {
+        issue();
+        stage(smem);
+        if (nchunks > 1) issue();
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks && !(a.debug & 2)) {
+                stage(smem + ((c + 1) & 1) * TILE);     // chunk c+1 (its loads flew during chunk c-1)
+                if (c + 2 < nchunks) issue();           // chunk c+2 flies during chunk c+1
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(1);      // math waves win issue arbitration over their loader partners
+        for (int c = 0; c < nchunks; ++c) {
+            if (a.debug & 1) {
+                __syncthreads();
+                continue;
+            }
+            const float* As = smem + (c & 1) * TILE;
+            const float* Bs = As + BM * IG_LD;
+            // operand fragments are double-buffered in registers: group g+1 is read from LDS while
+            // the 8*TN MFMAs of group g run, so only the first read after the barrier is exposed
+            float4 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = uda_ld4(&As[(arow + 32 * i) * IG_LD + koff]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + koff]);
+#pragma unroll
+            for (int g = 0; g < IG_BK / 8; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                if (g + 1 < IG_BK / 8) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[nxt][i] = uda_ld4(&As[(arow + 32 * i) * IG_LD + (g + 1) * 8 + koff]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[nxt][j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + (g + 1) * 8 + koff]);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float4 a4 = af[cur][i];
+                        const float av = s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float4 b4 = bf[cur][j];
+                            const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const int colb = n0 + wn * (32 * TN) + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = colb + 32 * j;
+            const bool cok = col < a.Cout;
+            const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (cok && row < P) {
+                        float v = acc[i][j][r] + bv;
+                        s1[j] += v;
+                        s2[j] += v * v;
+                        if (a.addend) v += a.addend[row * a.ld_add + col];
+                        a.y[row * a.ldy + col] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.part) {            // uniform over the workgroup
+        float* red = smem;   // [2 (wm)][2][BN]
+        if (!loader) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+                const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+                if (lane < 32) {
+                    const int cl = wn * (32 * TN) + 32 * j + lane;
+                    red[(wm * 2 + 0) * BN + cl] = t1;
+                    red[(wm * 2 + 1) * BN + cl] = t2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 512) {
+            const int qd = e / BN, cl = e % BN;
+            if (n0 + cl < a.Cout)
+                a.part[((int64_t)mt * 2 + qd) * a.Cout + n0 + cl] = red[(0 * 2 + qd) * BN + cl] + red[(1 * 2 + qd) * BN + cl];
+        }
+    }
+}
+
+template <int KS, int XF, int TN>
+static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
+    constexpr int BN = 64 * TN;
+    constexpr size_t lds = 2 * (128 + BN) * IG_LD * sizeof(float);
+    static bool configured = false;
+    auto fn = igemm_conv_ws_kernel<KS, XF, TN>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return uda_set_error("igemm_conv_ws: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        configured = true;
+    }
+    k.nMt = uda_cdiv(P, 128);
+    k.nNt = uda_cdiv(k.Cout, BN);
+    static const int dbg = getenv("UDA_WS_DEBUG") ? atoi(getenv("UDA_WS_DEBUG")) : 0;
+    k.debug = dbg;
+    hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3(512), lds, st, k);
+    UDA_LAUNCH_CHECK("igemm_conv_ws");
+    return 0;
+}
+
+template <int KS, int TN>
+static int launch_ws_xf(ConvKArgs& k, int64_t P, hipStream_t st) {
+    if (k.src.mask) return launch_ws<KS, 2, TN>(k, P, st);
+    if (k.src.scale) return launch_ws<KS, 1, TN>(k, P, st);
+    if (k.src.act != ACT_NONE) return launch_ws<KS, 1, TN>(k, P, st);
+    return launch_ws<KS, 0, TN>(k, P, st);
+}
+
+template <int KS>
+static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, hipStream_t st) {
+    switch (tn) {
+        case 2: return launch_ws_xf<KS, 2>(k, P, st);
+        case 3: return launch_ws_xf<KS, 3>(k, P, st);
+        case 4: return launch_ws_xf<KS, 4>(k, P, st);
+        default: return launch_ws_xf<KS, 5>(k, P, st);
+    }
+}
+
+int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
+    const int64_t lim = (int64_t)1 << 31;
+    UDA_REQUIRE((P + 128) * k.src.ldx < lim && (P + 128) * (k.src.mask ? k.src.ldm : 1) < lim && (int64_t)(k.Cout + 320) * k.Ktot < lim,
+                "uda_conv_fwd: operand too large for the 32-bit element offsets of the wide-tile kernel");
+    // Tile width BN = 64*TN chosen by a wave-quantisation model: workgroups run one per CU, a K-chunk
+    // costs ~TN MFMA-units, so time ~ ceil(#tiles / 256 CUs) * TN.  E.g. Cout = 304 at P = 262144 ->
+    // TN = 5 (one 320-wide tile, 5 % padding); Cout = 320 at P = 16384 -> TN = 3 (256 workgroups).
+    const int64_t nMt = uda_cdiv(P, 128);
+    int best = 2;
+    int64_t best_cost = -1;
+    for (int tn = 2; tn <= 5; ++tn) {
+        const int64_t tiles = nMt * uda_cdiv(k.Cout, 64 * tn);
+        const int64_t cost = ((tiles + 255) / 256) * tn * 16 + (tn == 2 ? 3 : 0);   // BN=128 stages A twice as often
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = tn;
+        }
+    }
+    return k.ksize == 3 ? launch_ws_tn<3>(k, P, best, st) : launch_ws_tn<1>(k, P, best, st);
+}
+
+// ==========================================================================================
+// Weight gradient, 128 (co) x 128 (j) tiles, same two-role structure.  Operand tiles are [pixel][row].
+template <int KS, int XF>
+__global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int TILE = WG_BKP * (BM + BN);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const int cot = blockIdx.x / a.nJt, jt = blockIdx.x % a.nJt;
+    const int split = blockIdx.y;
+    const int H = a.src.H, W = a.src.W, C = a.src.C;
+    const int64_t P = (int64_t)a.src.N * H * W;
+    const int c0 = split * a.chunks_per_split;
+    const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+
+    // loader mapping: 32 float4 per staged row, 8 pixel rows per pass, 4 passes
+    const int lt = tid & 255;
+    const int cv = (lt & 31) * 4, pr = lt >> 5;
+    const int co = cot * BM + cv;
+    const int j0 = jt * BN + cv;
+    const bool jok = j0 < a.Jtot;
+    int t = 0, ci = j0;
+    if (KS == 3 && jok) {
+        t = j0 / a.Kc;
+        ci = j0 - t * a.Kc;
+    }
+    int dh = 0, dw = 0;
+    if (KS == 3) {
+        dh = (t / 3 - 1) * a.dil;
+        dw = (t % 3 - 1) * a.dil;
+    }
+    Xf4 xf;
+    if (XF >= 1) uda_load_xf4(xf, a.src.scale, a.src.shift, ci, jok ? C : 0);
+    const int act = a.src.act;
+    const float ms = a.src.mask_scale;
+    const bool ctail = (C & 3) != 0, cotail = (a.Cout & 3) != 0;
+    float4 areg[4], breg[4];
+    uint32_t bmask[4];
+    unsigned bok = 0;
+    // per staged pixel row: pixel index and (h, w), advanced by 32 pixels per chunk without divisions
+    int pp[4], hh0[4], ww0[4];
+    if (loader) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t p = (int64_t)c0 * WG_BKP + pr + i * 8;
+            const int q = (int)(p < P ? p : 0);
+            pp[i] = (int)p;
+            ww0[i] = q % W;
+            hh0[i] = (q / W) % H;
+        }
+    }
+    const int ldx = (int)a.src.ldx, ldm = (int)a.src.ldm, lddy = (int)a.lddy;
+    const int tapoff = dh * W + dw;
+
+    auto issue = [&]() {
+        bok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool pin = pp[i] < (int)P;
+            areg[i] = (pin && co < a.Cout) ? uda_ld4(a.dy + (pp[i] * lddy + co)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bmask[i] = 0;
+            const int hh = hh0[i] + dh, ww = ww0[i] + dw;
+            if (jok && pin && hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                const int q = pp[i] + tapoff;
+                breg[i] = uda_ld4(a.src.x + (q * ldx + ci));
+                if (XF == 2) bmask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + (q * ldm + ci));
+                bok |= 1u << i;
+            }
+            // advance this row by one chunk (32 pixels)
+            pp[i] += WG_BKP;
+            ww0[i] += WG_BKP;
+            while (ww0[i] >= W) {
+                ww0[i] -= W;
+                if (++hh0[i] >= H) hh0[i] = 0;
+            }
+        }
+    };
+    auto stage = [&](float* buf) {
+        float* As = buf;
+        float* Bs = buf + WG_BKP * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            if (cotail) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (co + j >= a.Cout) v[j] = 0.f;
+            }
+            uda_st4(&As[(pr + i * 8) * BM + cv], make_float4(v[0], v[1], v[2], v[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[4] = {breg[i].x, breg[i].y, breg[i].z, breg[i].w};
+            const bool ok = (bok >> i) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j];
+                if (XF >= 1) {
+                    float mul = ok ? 1.f : 0.f;
+                    if (XF == 2) mul = (float)((bmask[i] >> (8 * j)) & 0xffu) * ms;
+                    u = uda_act(u * xf.sc[j] + xf.sh[j], act) * mul;
+                }
+                if (ctail && (ci + j) >= C) u = 0.f;
+                v[j] = u;
+            }
+            uda_st4(&Bs[(pr + i * 8) * BN + cv], make_float4(v[0], v[1], v[2], v[3]));
+        }
+    };
+
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
+    const int acol = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), kh = lane >> 5;
+    const int n = c1 - c0;
+    if (loader) {
+        if (n > 0) {
+            issue();
+            stage(smem);
+            if (n > 1) issue();
+        }
+        __syncthreads();
+        for (int c = 0; c < n; ++c) {
+            if (c + 1 < n) {
+                stage(smem + ((c + 1) & 1) * TILE);
+                if (c + 2 < n) issue();
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        for (int c = 0; c < n; ++c) {
+            const float* As = smem + (c & 1) * TILE;
+            const float* Bs = As + WG_BKP * BM;
+#pragma unroll
+            for (int kk = 0; kk < WG_BKP / 2; ++kk) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + kh) * BM + acol + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kk + kh) * BN + bcol + 32 * j];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        float* slab = a.slab + (int64_t)split * a.Cout * a.Jtot;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = jt * BN + wn * 64 + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = cot * BM + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < a.Cout && col < a.Jtot) slab[(int64_t)row * a.Jtot + col] = acc[i][j][r];
+                }
+            }
+    }
+}
+
+template <int KS, int XF>
+static int launch_wg(WgradKArgs& k, int S, hipStream_t st) {
+    constexpr size_t lds = 2 * WG_BKP * 256 * sizeof(float);
+    static bool configured = false;
+    auto fn = igemm_wgrad_ws_kernel<KS, XF>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return uda_set_error("igemm_wgrad_ws: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(k.nCot * k.nJt, S), dim3(512), lds, st, k);
+    UDA_LAUNCH_CHECK("igemm_wgrad_ws");
+    return 0;
+}
+
+int launch_wgrad_ws(WgradKArgs& k, int S, hipStream_t st) {
+    const int64_t lim = (int64_t)1 << 31, P = (int64_t)k.src.N * k.src.H * k.src.W;
+    UDA_REQUIRE((P + 64) * k.src.ldx < lim && (P + 64) * k.lddy < lim && (P + 64) * (k.src.mask ? k.src.ldm : 1) < lim,
+                "uda_conv_wgrad: operand too large for the 32-bit element offsets of the wide-tile kernel");
+    const int xf = k.src.mask ? 2 : ((k.src.scale || k.src.act != ACT_NONE) ? 1 : 0);
+    if (k.ksize == 3) return xf == 2 ? launch_wg<3, 2>(k, S, st) : xf == 1 ? launch_wg<3, 1>(k, S, st) : launch_wg<3, 0>(k, S, st);
+    return xf == 2 ? launch_wg<1, 2>(k, S, st) : xf == 1 ? launch_wg<1, 1>(k, S, st) : launch_wg<1, 0>(k, S, st);
+}

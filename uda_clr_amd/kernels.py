@@ -73,6 +73,16 @@ SYMBOLS = {
     "uda_gap_fwd": (_I, [_P, _L, _I, _I, _I, _F, _P, _L, _P]),
     "uda_broadcast_rows": (_I, [_P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _P]),
     "uda_dropout_mask": (_I, [_P, _L, _L, _I, _F, _U, _U, _P]),
+    "uda_seg_loss_fwd": (_I, [_P, _P, _L, _P, _P, _L, _P, _P, _P]),
+    "uda_seg_loss_bwd": (_I, [_P, _P, _L, _P, _P, _L, _P, _P, _P, _P]),
+    "uda_seg_counts": (_I, [_P, _P, _I, _I, _L, _F, _P, _P]),
+    "uda_mc_stats": (_I, [_P, _I, _L, _P, _P, _P]),
+    "uda_proto_weights": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "uda_proto_workspace_bytes": (_U, [_L, _I]),
+    "uda_proto_reduce": (_I, [_P, _L, _L, _I, _P, _P, _P, _U, _P]),
+    "uda_proto_finalize": (_I, [_P, _I, _P, _P]),
+    "uda_proto_bwd": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
 }
 
 
@@ -368,3 +378,98 @@ class HipKernels:
         assert mask.dtype == torch.uint8 and mask.stride(1) == 1
         self._ck(self.lib.uda_dropout_mask(mask.data_ptr(), mask.stride(0), mask.shape[0], mask.shape[1], p,
                                            int(seed), int(offset), self._stream()))
+
+    # ------------------------------------------------------------------ losses / metrics
+    def seg_loss_fwd(self, o, tmap, b, tbd):
+        """-> device float[3] = (BCE(sigmoid(o), map) + MSE(sigmoid(b), boundary), bce, mse)"""
+        for t in (o, tmap, b, tbd):
+            self._dev(t)
+            assert t.is_contiguous()
+        assert o.shape == tmap.shape and b.shape == tbd.shape
+        loss = torch.empty(3, dtype=torch.float32, device=o.device)
+        ws = torch.empty(2, dtype=torch.float64, device=o.device)
+        self._ck(self.lib.uda_seg_loss_fwd(o.data_ptr(), tmap.data_ptr(), o.numel(), b.data_ptr(), tbd.data_ptr(),
+                                           b.numel(), loss.data_ptr(), ws.data_ptr(), self._stream()))
+        return loss
+
+    def seg_loss_bwd(self, o, tmap, b, tbd, gscale):
+        d_o, d_b = torch.empty_like(o), torch.empty_like(b)
+        assert gscale.numel() == 1 and gscale.dtype == torch.float32
+        self._ck(self.lib.uda_seg_loss_bwd(o.data_ptr(), tmap.data_ptr(), o.numel(), b.data_ptr(), tbd.data_ptr(),
+                                           b.numel(), gscale.data_ptr(), d_o.data_ptr(), d_b.data_ptr(), self._stream()))
+        return d_o, d_b
+
+    def seg_counts(self, logits, target, thr):
+        """-> int64 [C, 3] = (intersection, predicted, ground truth) for sigmoid(logits) > thr"""
+        self._dev(logits)
+        assert logits.is_contiguous() and target.is_contiguous() and logits.shape == target.shape
+        B, Cc, H, W = logits.shape
+        counts = torch.empty(Cc, 3, dtype=torch.int64, device=logits.device)
+        self._ck(self.lib.uda_seg_counts(logits.data_ptr(), target.data_ptr(), B, Cc, H * W, thr, counts.data_ptr(),
+                                         self._stream()))
+        return counts
+
+    # ------------------------------------------------------------------ prototypes
+    def mc_stats(self, preds, T):
+        self._dev(preds)
+        assert preds.is_contiguous() and preds.shape[0] % T == 0
+        shape = (preds.shape[0] // T,) + tuple(preds.shape[1:])
+        std = torch.empty(shape, dtype=torch.float32, device=preds.device)
+        mean = torch.empty_like(std)
+        self._ck(self.lib.uda_mc_stats(preds.data_ptr(), T, std.numel(), std.data_ptr(), mean.data_ptr(), self._stream()))
+        return std, mean
+
+    def proto_weights(self, mode, B, h, w, map_=None, logits=None, std_map=None, mean_map=None):
+        dev = (map_ if map_ is not None else logits).device
+        P = B * h * w
+        wts = torch.empty(P, 4, dtype=torch.float32, device=dev)
+        H = W = 0
+        m0 = m1 = None
+        if mode == 0:
+            assert map_.is_contiguous() and map_.shape[:2] == (B, 2)
+            H, W = map_.shape[2], map_.shape[3]
+        if mode in (1, 2):
+            assert logits.shape == (P, 2) and logits.stride(1) == 1
+        if mode == 2:
+            assert std_map.is_contiguous() and mean_map.is_contiguous() and std_map.shape == mean_map.shape
+            H, W = std_map.shape[2], std_map.shape[3]
+            m0 = torch.empty(P, dtype=torch.float32, device=dev)
+            m1 = torch.empty(P, dtype=torch.float32, device=dev)
+        self._ck(self.lib.uda_proto_weights(mode, B, h, w, H, W, _ptr(map_), _ptr(logits),
+                                            0 if logits is None else logits.stride(0), _ptr(std_map), _ptr(mean_map),
+                                            wts.data_ptr(), _ptr(m0), _ptr(m1), self._stream()))
+        return wts, m0, m1
+
+    def proto_reduce(self, feat, wts, sums):
+        self._dev(feat)
+        f, ldf = _mat(feat, "feat")
+        P, Cc = feat.shape
+        assert wts.shape == (P, 4) and wts.is_contiguous() and sums.dtype == torch.float64 and tuple(sums.shape) == (4, Cc + 1)
+        ws = self._ws(feat, self.lib.uda_proto_workspace_bytes(P, Cc))
+        self._ck(self.lib.uda_proto_reduce(f, ldf, P, Cc, wts.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           self._stream()))
+
+    def proto_finalize(self, sums):
+        Cc = sums.shape[1] - 1
+        cent = torch.empty(4, Cc, dtype=torch.float32, device=sums.device)
+        self._ck(self.lib.uda_proto_finalize(sums.data_ptr(), Cc, cent.data_ptr(), self._stream()))
+        return cent
+
+    def proto_bwd(self, feat, wts, sums, dC, d_feat=None, accumulate=False, want_dw=False):
+        f, ldf = _mat(feat, "feat")
+        P, Cc = feat.shape
+        assert dC.is_contiguous() and tuple(dC.shape) == (4, Cc) and dC.dtype == torch.float32
+        coef = torch.empty(4, Cc + 1, dtype=torch.float32, device=feat.device)
+        d_w = torch.empty(P, 4, dtype=torch.float32, device=feat.device) if want_dw else None
+        dptr, ldd = (None, 0) if d_feat is None else _mat(d_feat, "d_feat")
+        self._ck(self.lib.uda_proto_bwd(f, ldf, P, Cc, wts.data_ptr(), sums.data_ptr(), dC.data_ptr(), coef.data_ptr(),
+                                        dptr, ldd, int(accumulate), _ptr(d_w), self._stream()))
+        return d_w
+
+    # ------------------------------------------------------------------ optimiser
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+        for t in (params, grads, exp_avg, exp_avg_sq):
+            self._dev(t)
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() == params.numel()
+        self._ck(self.lib.uda_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                        params.numel(), lr, beta1, beta2, eps, int(step), self._stream()))

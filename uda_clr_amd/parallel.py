@@ -59,6 +59,13 @@ class AllReduceSum(torch.autograd.Function):
         return g
 
 
+def all_reduce_sum_(t):
+    """In-place sum over the data-parallel ranks (no-op for a single process)."""
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def shard_indices(n, rank, world_size):
     """Dataset index striding by rank."""
     return list(range(rank, n, world_size))

@@ -1,0 +1,181 @@
+"""Shared host logic of the Trainer classes: logging, checkpoints, validation, data-parallel
+bootstrap.  Nothing here touches the reference; behaviour follows the cited lines of
+``train_process/Trainer_baseline.py`` / ``Trainer_prototype_full.py``."""
+from __future__ import annotations
+
+import math
+import os
+import os.path as osp
+import socket
+from datetime import datetime, timedelta, timezone
+
+import torch
+import torch.distributed as dist
+
+try:  # optional, absent in this image
+    from tensorboardX import SummaryWriter  # type: ignore
+except Exception:  # noqa: BLE001
+    class SummaryWriter:  # minimal stand-in: scalars/images are dropped
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def add_image(self, *a, **k): pass
+        def close(self): pass
+
+try:
+    import pytz  # type: ignore
+    _TZ = pytz.timezone('Asia/Hong_Kong')
+except Exception:  # noqa: BLE001
+    _TZ = timezone(timedelta(hours=8))
+
+try:
+    import tqdm  # type: ignore
+    def progress(it, **k): return tqdm.tqdm(it, **k)
+    def trange(*a, **k): return tqdm.trange(*a, **k)
+except Exception:  # noqa: BLE001
+    def progress(it, **k): return it
+    def trange(*a, **k): return range(*a)
+
+
+def now():
+    return datetime.now(_TZ)
+
+
+def get_lr(optimizer):
+    for g in optimizer.param_groups:
+        return g['lr']
+
+
+class HipOps:
+    """The device ops a Trainer uses (tests may hand a Trainer another object with these names)."""
+    def __init__(self):
+        from .. import ops
+        from ..utils import metrics
+        self.seg_loss = ops.seg_loss
+        self.gen_prototype_from_labels = ops.gen_prototype_from_labels
+        self.gen_prototype = ops.gen_prototype
+        self.gen_prototype_retrify = ops.gen_prototype_retrify
+        self.dice_coeff_2label = metrics.dice_coeff_2label
+        self.pixel_acc = metrics.pixel_acc
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def bootstrap_from_env():
+    """One process per GPU (torch.distributed.run / torchrun env): pick the local device and join
+    the RCCL group before the unchanged entry script calls ``.cuda()``."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or not dist.is_available() or dist.is_initialized():
+        return
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
+
+
+class _Strided:
+    """rank-strided view of a loader (dataset index striding)."""
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __len__(self):
+        n = len(self.loader)
+        return (n - self.rank + self.world - 1) // self.world if n > self.rank else 0
+
+    def __iter__(self):
+        for i, b in enumerate(self.loader):
+            if i % self.world == self.rank:
+                yield b
+
+
+def shard_loader(loader, rank, world):
+    """Every rank sees a disjoint 1/world of the BATCHES of an epoch.  DataLoaders are rebuilt over
+    a rank-strided subset of their dataset (keeps batch size / workers / collate); plain sequences
+    are strided directly."""
+    if world == 1 or loader is None:
+        return loader
+    from torch.utils.data import DataLoader, Subset
+    if isinstance(loader, DataLoader):
+        idx = list(range(rank, len(loader.dataset), world))
+        return DataLoader(Subset(loader.dataset, idx), batch_size=loader.batch_size,
+                          shuffle=isinstance(loader.sampler, torch.utils.data.RandomSampler),
+                          num_workers=loader.num_workers, pin_memory=loader.pin_memory,
+                          collate_fn=loader.collate_fn, drop_last=loader.drop_last)
+    return _Strided(loader, rank, world)
+
+
+def nan_guard(values, what):
+    for v in values:
+        if math.isnan(v):
+            raise ValueError('%s is nan while training' % what)
+
+
+class TrainerBase(object):
+    log_headers = []
+
+    def _setup_io(self, out):
+        self.rank, self.world = rank_world()
+        self.out = out
+        self.timestamp_start = now()
+        if self.rank == 0:
+            if not osp.exists(out):
+                os.makedirs(out)
+            if not osp.exists(osp.join(out, 'log.csv')):
+                with open(osp.join(out, 'log.csv'), 'w') as f:
+                    f.write(','.join(self.log_headers) + '\n')
+            log_dir = osp.join(out, 'tensorboard', datetime.now().strftime('%b%d_%H-%M-%S') + '_' + socket.gethostname())
+            self.writer = SummaryWriter(log_dir=log_dir)
+        else:
+            self.writer = SummaryWriter.__new__(SummaryWriter) if False else _NullWriter()
+
+    def _device(self):
+        return next(self.model_gen.parameters()).device
+
+    def _to(self, t):
+        return t.to(self._device(), non_blocking=True)
+
+    def _log_row(self, fields):
+        if self.rank != 0:
+            return
+        with open(osp.join(self.out, 'log.csv'), 'a') as f:
+            f.write(','.join(map(str, fields)) + '\n')
+
+    def elapsed(self):
+        return (now() - self.timestamp_start).total_seconds()
+
+    # ---------------------------------------------------------------- validation (Trainer_*.validate)
+    def _validate_core(self):
+        """eval-mode pass over val_loader: mean BCE-with-logits, batch-level Dice (cup, disc) and
+        PA / IoU, averaged over BATCHES (Trainer_prototype_full.py:110-159)."""
+        import torch.nn.functional as F
+        n = len(self.val_loader)
+        acc = [0.0] * 7
+        with torch.no_grad():
+            for sample in progress(self.val_loader, total=n, desc='Valid iteration=%d' % self.iteration, ncols=80, leave=False):
+                data, target_map = self._to(sample['image']), self._to(sample['map'])
+                predictions = self.model_gen(data)[0]
+                loss = F.binary_cross_entropy_with_logits(predictions, target_map).item()
+                if math.isnan(loss):
+                    raise ValueError('loss is nan while validating')
+                dc, dd = self.ops.dice_coeff_2label(predictions, target_map)
+                pc, pd, ic, idc = self.ops.pixel_acc(predictions, target_map)
+                for i, v in enumerate((loss, dc, dd, pc, pd, ic, idc)):
+                    acc[i] += v
+        return [v / max(n, 1) for v in acc]
+
+    def _lr_schedule(self, epoch):
+        """every 100 epochs lr = lr_gen * 0.2, not cumulative (quirk Q9, Trainer_prototype_full.py:637-640)"""
+        if (epoch + 1) % 100 == 0:
+            for g in self.optim_gen.param_groups:
+                g['lr'] = self.lr_gen * 0.2
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k): pass
+    def add_image(self, *a, **k): pass
+    def close(self): pass

@@ -4,10 +4,11 @@
     python bench.py --gpus N --steps K --warmup W            (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic 512x512 inputs resident in HBM:
-workload ``source_only`` (BASELINE.json configs[1]): zero_grad -> DeepLabV3+/MobileNetV2 forward
-(training-mode BN, device-generated dropout) -> BCE+MSE seg loss -> backward -> Adam step, B=16/GPU
-(Trainer_baseline.py:198-243).  Data parallel: one process per GPU, per-rank batch fixed (weak
+One "step" = one pass of the hot path over one batch of synthetic 512x512 inputs resident in HBM.
+Default workload ``prototype_full`` (BASELINE.json configs[2], the one the metric "src+tgt" is quoted
+on): one Trainer_prototype_full iteration with B=16 source + 16 target images per GPU
+(Trainer_prototype_full.py:261-517).  ``--workload source_only`` (configs[1]): zero_grad -> generator
+forward -> BCE+MSE seg loss -> backward -> Adam (Trainer_baseline.py:198-243).  Data parallel: one process per GPU, per-rank batch fixed (weak
 scaling), one flat RCCL all-reduce of the generator gradients per step; BN statistics stay per rank
 as in the reference.  Rank 0 prints ONE JSON line with the metric, the roofline of the dominant
 kernel (FP32-MFMA implicit-GEMM 3x3 convolutions, timed live with HIP events on the launch stream)
@@ -74,30 +75,42 @@ class ConvTimer:
         tf = sum(self.flops) / (sum(ms) * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "igemm_conv_kernel<2,2,2,2> (3x3 fwd+dgrad, decoder+ASPP)",
+                "kernel": "igemm_conv_ws_kernel<3,*,*> (3x3 implicit GEMM: forward + input-gradient of the decoder and ASPP convs)",
                 "launches": len(ms), "avg_launch_ms": round(sum(ms) / len(ms), 4),
                 "algorithmic_gflop_per_launch": round(sum(self.flops) / len(ms) / 1e9, 2)}
 
 
-def cpu_baseline(B, S, steps):
+def cpu_baseline(workload, B, S):
     """The oracle restatement of the same step on the host cores (bounded sample)."""
     from oracle import deeplab_ref, step_ref
+    from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
     from uda_clr_amd.networks.deeplabv3 import DeepLab
     torch.manual_seed(1337)
     sd = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16).state_dict()
     om = deeplab_ref.OracleDeepLab(sd).train()
-    opt = torch.optim.Adam(om.parameters(), lr=1e-3, betas=(0.9, 0.99))
     img, tmap, tbd = synth_batch(B, S, 1337, "cpu")
-    step_ref.baseline_step(om, opt, img, tmap, tbd)            # warm-up
+    imgT = synth_batch(B, S, 4242, "cpu")[0]
+    if workload == "source_only":
+        opt = torch.optim.Adam(om.parameters(), lr=1e-3, betas=(0.9, 0.99))
+        run = lambda: step_ref.baseline_step(om, opt, img, tmap, tbd)
+        n_img, steps = B, 5
+    else:
+        d1, d2 = BoundaryDiscriminator().train(), UncertaintyDiscriminator().train()
+        og, od, od2 = step_ref.make_optimizers(om, d1, d2)
+        stepper = step_ref.PrototypeFullStep(om, d1, d2, og, od, od2)
+        run = lambda: stepper(img, tmap, tbd, imgT)
+        n_img, steps = 2 * B, 1
+    run()            # warm-up
     ts = []
     for _ in range(steps):
         t0 = time.perf_counter()
-        step_ref.baseline_step(om, opt, img, tmap, tbd)
+        run()
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"value": round(B / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps (median) of the source-only step at B=%d, %dx%d on the host cores" % (steps, B, S, S)}
+    return {"value": round(n_img / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d step(s) (median) of the %s step at B=%d%s, %dx%d, oracle restatement on the host cores"
+                      % (steps, workload, B, "" if workload == "source_only" else "+%d" % B, S, S)}
 
 
 def main():
@@ -105,8 +118,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="source (and target) images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--workload", choices=("prototype_full", "source_only"), default="prototype_full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,26 +137,48 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from uda_clr_amd.kernels import load_library
+    from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
     from uda_clr_amd.networks.deeplabv3 import DeepLab
-    from uda_clr_amd.parallel import FlatGradAllReduce
+    from uda_clr_amd.train_process import Trainer_baseline, Trainer_prototype_full
     load_library()
     torch.manual_seed(1337)
     model = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True, freeze_bn=False,
-                    method="baseline").to(dev).train()
+                    method=args.workload).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.99))
-    bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss()
     img, tmap, tbd = synth_batch(args.batch, args.size, 1337 + rank, dev)
-    reducer = FlatGradAllReduce(list(model.parameters())) if world > 1 else None
+    imgT = synth_batch(args.batch, args.size, 4242 + rank, dev)[0]
+    sampleS = {"image": img, "map": tmap, "boundary": tbd}
+    sampleT = {"image": imgT}
+    out = os.path.join("/tmp", "uda_bench_%d" % os.getpid())
+    if args.workload == "source_only":
+        tr = Trainer_baseline.Trainer(cuda=True, model_gen=model, optimizer_gen=opt, val_loader=[], domain_loaderS=[],
+                                      domain_loaderT=[], out=out, max_epoch=1, batch_size=args.batch, warmup_epoch=-1)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        oS, bS = model(img)[:2]
-        loss = bce(torch.sigmoid(oS), tmap) + mse(torch.sigmoid(bS), tbd)
-        loss.backward()
-        if reducer is not None:
-            reducer.all_reduce_mean()
-        opt.step()
-        return loss
+        def step():
+            # Trainer_baseline.train_epoch body for one device-resident batch
+            opt.zero_grad(set_to_none=True)
+            oS, bS = model(img)[:2]
+            loss = tr.ops.seg_loss(oS, bS, tmap, tbd)
+            loss.backward()
+            if tr._reducer is not None:
+                tr._reducer.all_reduce_mean()
+            opt.step()
+            return loss
+        per_step = args.batch
+    else:
+        d1, d2 = BoundaryDiscriminator().to(dev).train(), UncertaintyDiscriminator().to(dev).train()
+        od = torch.optim.SGD(d1.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=5e-4)
+        od2 = torch.optim.SGD(d2.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=5e-4)
+        tr = Trainer_prototype_full.Trainer(
+            cuda=True, model_gen=model, model_dis=d1, model_uncertainty_dis=d2, optimizer_gen=opt, optimizer_dis=od,
+            optimizer_uncertainty_dis=od2, val_loader=[], domain_loaderS=[], domain_loaderT=[], out=out, max_epoch=1,
+            use_global=True, use_pid=True, retrify_pesudo=True, global_pro_weight=0.9, pro_weight=0.1, batch_size=args.batch,
+            warmup_epoch=-1)
+        tr.epoch = 0
+
+        def step():
+            return tr.train_step(sampleS, sampleT)
+        per_step = 2 * args.batch          # source + target images (the metric counts both)
 
     for _ in range(args.warmup):
         step()
@@ -157,7 +193,7 @@ def main():
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        last = step()
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -165,22 +201,27 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    final_loss = loss.item()
+    losses = [round(float(v), 5) for v in (last if isinstance(last, list) else [last.item()])]
     if rank == 0:
-        images = args.batch * world * args.steps
+        images = per_step * world * args.steps
+        desc = {"source_only": "source_only: Trainer_baseline step (fwd, BCE+MSE, bwd, Adam), DeepLabV3+/MobileNetV2 %dx%d "
+                               "bs=%d/GPU (BASELINE.json configs[1]); source images only",
+                "prototype_full": "prototype_full: Trainer_prototype_full step (T+S generator fwd/bwd, seg loss, source/target "
+                                  "prototypes with 4 MC-dropout passes (T=8), retrified pseudo labels, EMA, alignment loss, "
+                                  "adversarial G/D steps), DeepLabV3+/MobileNetV2 %dx%d bs=%d src + %d tgt per GPU "
+                                  "(BASELINE.json configs[2]; images/sec counts src+tgt)"}[args.workload]
+        fmt = (args.size, args.size, args.batch) + ((args.batch,) if args.workload == "prototype_full" else ())
         line = {
             "metric": "training images/sec (512x512, src+tgt) at 1/2/4/8 MI355X; val Dice vs ref",
             "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "source_only: Trainer_baseline step, DeepLabV3+/MobileNetV2 %dx%d bs=%d/GPU "
-                                   "(BASELINE.json configs[1]); source images only" % (args.size, args.size, args.batch),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "final_loss": round(final_loss, 5)},
+            "config": {"workload": desc % fmt, "global_batch": per_step * world, "parallelism": "dp%d" % world,
+                       "last_step_losses": losses},
             "roofline": timer.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(2, args.size, 5)
+            line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -26,6 +26,10 @@
 extern "C" {
 #endif
 
+/* Per-channel statistics are accumulated with fp64 atomics into UDA_STAT_SLOTS replicas
+ * (slot = workgroup index mod UDA_STAT_SLOTS, spreads contention); consumers sum the replicas. */
+#define UDA_STAT_SLOTS 16
+
 #define UDA_ACT_NONE 0
 #define UDA_ACT_RELU 1
 #define UDA_ACT_RELU6 2
@@ -59,7 +63,8 @@ int uda_relayout_dw(const float* w, int C, float* out, void* stream);
  * Replaces F.conv2d at mobilenet.py:43,49,57, aspp.py:50-53,56,59, decoder.py:20,32,33,37,41 and,
  * with uda_relayout_dgrad weights, their input-gradient.
  *   y[p,co] = bias[co] + addend[p,co] + sum_{t,ci} u(p+off_t, ci) * w[co][t][ci]
- * stats (optional, double[2][Cout], ADDED into): sum and sum of squares of y before addend. */
+ * stats (optional, double[UDA_STAT_SLOTS][2][Cout], ADDED into): sum and sum of squares of y
+ * before addend. */
 typedef struct uda_conv_args {
     uda_src_t src;
     const float* w;        /* [Cout][ksize*ksize][round4(src.C)] */
@@ -69,11 +74,8 @@ typedef struct uda_conv_args {
     int64_t ld_add;
     float* y;              /* [P, ldy] */
     int64_t ldy;
-    double* stats;         /* [2][Cout] or NULL */
-    float* workspace;      /* needed when stats != NULL */
-    uint64_t workspace_bytes;
+    double* stats;         /* [UDA_STAT_SLOTS][2][Cout] or NULL */
 } uda_conv_args_t;
-uint64_t uda_conv_workspace_bytes(int64_t P, int Cout);
 int uda_conv_fwd(const uda_conv_args_t* a, void* stream);
 
 /* weight gradient of the same convolution: dw[co][ci][kh][kw] = sum_p dy[p,co]*u(p+off_t,ci) */
@@ -93,8 +95,7 @@ int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream);
  * border_mode 0: out-of-image taps read 0; 1: they read act(shift[c]) (quirk Q1). */
 uint64_t uda_dwconv_workspace_bytes(int64_t Pout, int C);
 int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride, int dil, int border_mode,
-                   float* y, int64_t ldy, double* stats, float* workspace, uint64_t workspace_bytes,
-                   void* stream);
+                   float* y, int64_t ldy, double* stats /* [SLOTS][2][C] or NULL */, void* stream);
 int uda_dwconv_dgrad(const float* dy, int64_t lddy, const float* w9c, int C, int stride, int dil,
                      int N, int H, int W, float* dx, int64_t lddx, void* stream);
 int uda_dwconv_wgrad(const uda_src_t* src, const float* dy, int64_t lddy, int stride, int dil,
@@ -104,11 +105,12 @@ int uda_dwconv_wgrad(const uda_src_t* src, const float* dy, int64_t lddy, int st
 /* ---- stem conv 3x3 stride 2 pad 1, 3 -> 32, NCHW image in, NHWC out (mobilenet.py:10) */
 uint64_t uda_stem_workspace_bytes(int64_t Pout);
 int uda_stem_fwd(const float* x, int N, int H, int W, const float* w, float* y, int64_t ldy,
-                 double* stats, float* workspace, uint64_t workspace_bytes, void* stream);
+                 double* stats /* [SLOTS][2][32] or NULL */, void* stream);
 int uda_stem_wgrad(const float* x, int N, int H, int W, const float* dy, int64_t lddy, float* dw,
                    float* workspace, uint64_t workspace_bytes, void* stream);
 
 /* ---- batch-norm pieces (F.batch_norm, training and eval) */
+/* stats: double[UDA_STAT_SLOTS][2][C] */
 int uda_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale,
                     float* shift, float* mean, float* invstd, void* stream);
@@ -118,14 +120,12 @@ int uda_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* out = transform(src) + residual */
 int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t ldr, float* out, int64_t ldo,
                  void* stream);
-uint64_t uda_reduce_workspace_bytes(int64_t P, int C, int nq);
-/* out (double[nq][C], ADDED into): nq=1 sum, nq=2 sum and sum of squares of x */
-int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out,
-                 float* workspace, uint64_t workspace_bytes, void* stream);
-/* g = dU*mask*act'(a);  sums (double[3][C], ADDED into) = (sum g, sum g*xhat, sum dU) */
+/* out (double[UDA_STAT_SLOTS][nq][C], ADDED into): nq=1 sum, nq=2 sum and sum of squares of x */
+int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, void* stream);
+/* g = dU*mask*act'(a);  sums (double[UDA_STAT_SLOTS][3][C], ADDED into) = (sum g, sum g*xhat, sum dU) */
 int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
-                     const float* invstd, double* sums, float* workspace, uint64_t workspace_bytes,
-                     void* stream);
+                     const float* invstd, double* sums, void* stream);
+/* sums: double[UDA_STAT_SLOTS][3][C] */
 int uda_bnbwd_finalize(const double* sums, int C, double count, int q1_border, int act,
                        const float* shift, const float* mean, const float* invstd, float* c1,
                        float* c2, float* dgamma, float* dbeta, void* stream);

@@ -52,7 +52,7 @@ def conv_case(name, N, H, W, Cin, Cout, k, dil, lazy=False, mask=False, stats=Tr
         s = src(N, H, W, Cin, lazy, mask)
         w = K.relayout_ohwi(torch.randn(Cout, Cin, k, k, device=dev))
         out = torch.empty(s.P, round4(Cout), device=dev)[:, :Cout]
-        st = torch.zeros(2, Cout, dtype=torch.float64, device=dev) if stats else None
+        st = torch.zeros(16, 2, Cout, dtype=torch.float64, device=dev) if stats else None
         ms = timeit(lambda: K.conv(s, w, k, dil, out, stats=st))
         report(name, ms, 2.0 * s.P * Cout * k * k * Cin, 4.0 * s.P * (Cin + Cout))
     cases.append((name, run))
@@ -91,7 +91,7 @@ def ew_cases():
     y.bn = BNRec("t", torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5, float(P))
     dU = torch.randn(P, C, device=dev)
     c = torch.randn(4, C, device=dev)
-    sums = torch.zeros(3, C, dtype=torch.float64, device=dev)
+    sums = torch.zeros(16, 3, C, dtype=torch.float64, device=dev)
     report("bnbwd_reduce 256ch 128^2", timeit(lambda: K.bnbwd_reduce(dU, y, sums)), 0, P * C * 9.0)
     report("bnbwd_apply 256ch 128^2", timeit(lambda: K.bnbwd_apply(dU, y, c[0], c[1], dU)), 0, P * C * 13.0)
     for (Cc, H, s, d) in ((96, 256, 2, 1), (144, 128, 1, 1), (32, 256, 1, 1), (960, 32, 1, 2)):
@@ -100,7 +100,7 @@ def ew_cases():
         w9 = torch.randn(9, Cc, device=dev)
         Ho = (H - 1) // s + 1
         out = torch.empty(B * Ho * Ho, Cc, device=dev)
-        st = torch.zeros(2, Cc, dtype=torch.float64, device=dev)
+        st = torch.zeros(16, 2, Cc, dtype=torch.float64, device=dev)
         report("dw fwd C=%d %d^2 s%d" % (Cc, H, s), timeit(lambda: K.dwconv_fwd(a, w9, s, d, 1, out, st)), 0, 4.0 * Cc * B * (H * H + Ho * Ho))
         dy = torch.randn(B * Ho * Ho, Cc, device=dev)
         dw = torch.empty(Cc, 1, 3, 3, device=dev)

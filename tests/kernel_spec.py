@@ -99,8 +99,8 @@ class SpecKernels:
         w4 = w[:, :, :Cin].reshape(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
         y = _rows(F.conv2d(u, w4, bias, 1, dil * (ksize // 2), dil))
         if stats is not None:
-            stats[0] = y.double().sum(0)
-            stats[1] = (y.double() ** 2).sum(0)
+            stats[0, 0] += y.double().sum(0)
+            stats[0, 1] += (y.double() ** 2).sum(0)
         if addend is not None:
             y = y + addend
         out.copy_(y)
@@ -128,8 +128,8 @@ class SpecKernels:
         up = self._dw_input(src, dil, border_mode)
         y = _rows(F.conv2d(up, w9c.t().reshape(C, 1, 3, 3), None, stride, 0, dil, C))
         if stats is not None:
-            stats[0] = y.double().sum(0)
-            stats[1] = (y.double() ** 2).sum(0)
+            stats[0, 0] += y.double().sum(0)
+            stats[0, 1] += (y.double() ** 2).sum(0)
         out.copy_(y)
 
     def dwconv_dgrad(self, dy, w9c, stride, dil, N, H, W, out):
@@ -152,8 +152,8 @@ class SpecKernels:
     def stem_fwd(self, x, w, out, stats=None):
         y = _rows(F.conv2d(x, w, None, 2, 1))
         if stats is not None:
-            stats[0] = y.double().sum(0)
-            stats[1] = (y.double() ** 2).sum(0)
+            stats[0, 0] += y.double().sum(0)
+            stats[0, 1] += (y.double() ** 2).sum(0)
         out.copy_(y)
 
     def stem_wgrad(self, x, dy, dw):
@@ -166,8 +166,9 @@ class SpecKernels:
                     scale, shift, mean, invstd):
         """Training BN coefficients from (sum, sumsq) over ``count`` elements; updates the running
         statistics exactly like F.batch_norm (unbiased variance into running_var)."""
-        m = stats[0] / count
-        var = (stats[1] / count - m * m).clamp_min(0.0)
+        st = stats.sum(0)
+        m = st[0] / count
+        var = (st[1] / count - m * m).clamp_min(0.0)
         istd = 1.0 / torch.sqrt(var + eps)
         mean.copy_(m.float())
         invstd.copy_(istd.float())
@@ -189,8 +190,10 @@ class SpecKernels:
         out.copy_(u)
 
     def colstats(self, x, stats):
-        stats[0] = x.double().sum(0)
-        stats[1] = (x.double() ** 2).sum(0)
+        """stats: fp64 [SLOTS, nq, C], ADDED into (any slot; consumers sum the slots)."""
+        stats[0, 0] += x.double().sum(0)
+        if stats.shape[1] > 1:
+            stats[0, 1] += (x.double() ** 2).sum(0)
 
     def bnbwd_reduce(self, dU, y: Act, sums):
         """y carries (x, scale, shift, act, mask, bn.mean/invstd).  g = dU * mask*ms * act'(a);
@@ -200,13 +203,14 @@ class SpecKernels:
         if y.mask is not None:
             g = g * (y.mask.to(g.dtype) * y.mask_scale)
         xhat = (y.x - y.bn.mean) * y.bn.invstd
-        sums[0] = g.double().sum(0)
-        sums[1] = (g.double() * xhat.double()).sum(0)
-        sums[2] = dU.double().sum(0)
+        sums[0, 0] += g.double().sum(0)
+        sums[0, 1] += (g.double() * xhat.double()).sum(0)
+        sums[0, 2] += dU.double().sum(0)
 
     def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
         """Adds the border term of quirk Q1 when y.bn.q1_border, then c1 = sum g / n,
         c2 = sum g*xhat / n, dgamma = sum g*xhat, dbeta = sum g."""
+        sums = sums.sum(0)
         sg, sgx = sums[0].clone(), sums[1].clone()
         if y.bn.q1_border:
             sh = y.shift.double()
@@ -288,6 +292,8 @@ class SpecKernels:
 
     def colsum(self, x, out):
         out.copy_(x.double().sum(0).float())
+
+    STAT_SLOTS = 16
 
     def dropout_mask(self, mask, p, seed, offset):
         """Bernoulli(1-p) keep-mask (uint8).  The bit stream is implementation-defined (Philox on

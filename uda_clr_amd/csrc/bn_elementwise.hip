@@ -34,8 +34,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, doub
                                    float* __restrict__ mean, float* __restrict__ invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = stats[c] / count;
-    double var = stats[C + c] / count - m * m;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < UDA_STAT_SLOTS; ++k) {
+        s1 += stats[(k * 2 + 0) * C + c];
+        s2 += stats[(k * 2 + 1) * C + c];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     const double istd = 1.0 / sqrt(var + (double)eps);
     const double sc = (double)gamma[c] * istd;
@@ -79,15 +85,25 @@ extern "C" int uda_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 // ------------------------------------------------------------------------------------------
+#define EW_ITER 16
+// Elementwise kernels: channel group cg = tid % G is FIXED per thread (its per-channel coefficients
+// live in registers), pixel lane pl = tid / G walks EW_ITER strips of PP = 256/G pixels; channels
+// beyond 1024 go to blockIdx.y.
 __global__ __launch_bounds__(256) void bn_apply_kernel(uda_src_t s, const float* __restrict__ res, int64_t ldr,
                                                        float* __restrict__ out, int64_t ldo, int64_t P) {
-    const int C = s.C, G = (C + 3) >> 2;
-    const int64_t total = P * G;
+    const int C = s.C, cblk0 = blockIdx.y * RED_CBLK;
+    const int Cb = min(RED_CBLK, C - cblk0), G = (Cb + 3) >> 2, PP = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
+    if (pl >= PP) return;
+    const int c0 = cblk0 + cg * 4;
+    Xf4 xf;
+    uda_load_xf4(xf, s.scale, s.shift, c0, C);
     const bool has_xf = s.scale != nullptr;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(e % G);
-        const int64_t p = e / G;
-        const int c0 = cg * 4;
+    const int64_t base = (int64_t)blockIdx.x * (PP * EW_ITER);
+#pragma unroll 4
+    for (int it = 0; it < EW_ITER; ++it) {
+        const int64_t p = base + (int64_t)it * PP + pl;
+        if (p >= P) break;
         const float4 xv = uda_ld4(s.x + p * s.ldx + c0);
         float v[4] = {xv.x, xv.y, xv.z, xv.w};
         uint32_t mk = 0x01010101u;
@@ -99,15 +115,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uda_src_t s, const float*
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j;
             float u = v[j];
-            if (c < C) {
-                if (has_xf) u = u * s.scale[c] + s.shift[c];
-                u = uda_act(u, s.act);
-                if (s.mask) u *= ((mk >> (8 * j)) & 0xffu) ? s.mask_scale : 0.f;
-                u += r[j];
-            }
-            v[j] = u;
+            if (has_xf) u = u * xf.sc[j] + xf.sh[j];
+            u = uda_act(u, s.act);
+            if (s.mask) u *= (float)((mk >> (8 * j)) & 0xffu) * s.mask_scale;
+            v[j] = u + r[j];
         }
         st4_guard(out + p * ldo + c0, v, C - c0);
     }
@@ -122,10 +134,10 @@ static int src_check(const uda_src_t* s, const char* who) {
     return 0;
 }
 
-static inline int ew_grid(int64_t total) {
-    int g = uda_cdiv(total, 256);
-    if (g > 16384) g = 16384;
-    return g < 1 ? 1 : g;
+static inline dim3 ew_grid2(int64_t P, int C) {
+    const int Cb = C < RED_CBLK ? C : RED_CBLK;
+    const int PP = 256 / ((Cb + 3) / 4);
+    return dim3(uda_cdiv(P, (int64_t)PP * EW_ITER), uda_cdiv(C, RED_CBLK));
 }
 
 extern "C" int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream) {
@@ -133,8 +145,7 @@ extern "C" int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t
     UDA_REQUIRE(out && uda_aligned16(out) && ldo % 4 == 0 && ldo >= src->C, "uda_bn_apply: out must be 16-byte aligned, ldo %% 4 == 0");
     if (residual) UDA_REQUIRE(uda_aligned16(residual) && ldr % 4 == 0, "uda_bn_apply: residual must be 16-byte aligned");
     const int64_t P = (int64_t)src->N * src->H * src->W;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(P * ((src->C + 3) / 4))), dim3(256), 0, (hipStream_t)stream, *src,
-                       residual, ldr, out, ldo, P);
+    hipLaunchKernelGGL(bn_apply_kernel, ew_grid2(P, src->C), dim3(256), 0, (hipStream_t)stream, *src, residual, ldr, out, ldo, P);
     UDA_LAUNCH_CHECK("bn_apply");
     return 0;
 }
@@ -149,7 +160,7 @@ struct RedArgs {
     uda_src_t y;         // MODE 1
     const float* mean;
     const float* invstd;
-    float* part;         // [nWG][nq][C]
+    double* out;         // [UDA_STAT_SLOTS][nq][C], fp64 atomics
 };
 
 template <int MODE>
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
         const int q = e / Cb, c = e % Cb;
         float t = 0.f;
         for (int p = 0; p < PP; ++p) t += red[(q * PP + p) * Cp + c];
-        a.part[((int64_t)blockIdx.x * a.nq + q) * a.C + cblk0 + c] = t;
+        atomicAdd(&a.out[((int64_t)(blockIdx.x % UDA_STAT_SLOTS) * a.nq + q) * a.C + cblk0 + c], (double)t);
     }
 }
 
@@ -229,38 +240,31 @@ static inline int red_nwg(int64_t P, int C) {
     return uda_cdiv(P, (int64_t)PP * RED_ITER);
 }
 
-extern "C" uint64_t uda_reduce_workspace_bytes(int64_t P, int C, int nq) {
-    return (uint64_t)red_nwg(P, C) * nq * C * sizeof(float);
-}
-
-extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, float* workspace,
-                            uint64_t workspace_bytes, void* stream) {
+extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(x && uda_aligned16(x) && ldx % 4 == 0 && ldx >= ((C + 3) / 4) * 4 && P > 0 && C > 0 && (nq == 1 || nq == 2) && out,
                 "uda_colstats: bad args");
-    UDA_REQUIRE(workspace && workspace_bytes >= uda_reduce_workspace_bytes(P, C, nq), "uda_colstats: workspace too small");
     RedArgs a;
-    a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.part = workspace;
+    a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.out = out;
     const int nwg = red_nwg(P, C);
     hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nwg, uda_cdiv(C, RED_CBLK)), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("colstats");
-    return uda_reduce_partials(workspace, nwg, nq * C, out, st);
+    return 0;
 }
 
 extern "C" int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean, const float* invstd,
-                                double* sums, float* workspace, uint64_t workspace_bytes, void* stream) {
+                                double* sums, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (int e = src_check(y, "uda_bnbwd_reduce")) return e;
     UDA_REQUIRE(y->scale && mean && invstd && sums, "uda_bnbwd_reduce: needs scale/shift/mean/invstd");
     UDA_REQUIRE(dU && uda_aligned16(dU) && ldu % 4 == 0 && ldu >= ((y->C + 3) / 4) * 4, "uda_bnbwd_reduce: bad dU layout");
     const int64_t P = (int64_t)y->N * y->H * y->W;
-    UDA_REQUIRE(workspace && workspace_bytes >= uda_reduce_workspace_bytes(P, y->C, 3), "uda_bnbwd_reduce: workspace too small");
     RedArgs a;
-    a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.part = workspace;
+    a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.out = sums;
     const int nwg = red_nwg(P, y->C);
     hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nwg, uda_cdiv(y->C, RED_CBLK)), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("bnbwd_reduce");
-    return uda_reduce_partials(workspace, nwg, 3 * y->C, sums, st);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,11 +274,17 @@ __global__ void bnbwd_finalize_kernel(const double* __restrict__ sums, int C, do
                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double sg = sums[c], sgx = sums[C + c];
+    double sg = 0.0, sgx = 0.0, sdu = 0.0;
+#pragma unroll
+    for (int k = 0; k < UDA_STAT_SLOTS; ++k) {
+        sg += sums[(k * 3 + 0) * C + c];
+        sgx += sums[(k * 3 + 1) * C + c];
+        sdu += sums[(k * 3 + 2) * C + c];
+    }
     if (q1) {
         // quirk Q1: the zero border of the padded block input went through this BN; its upstream
         // gradients sum to -(sum of interior dU) because the depthwise BN backward is mean-free.
-        const double gb = -sums[2 * C + c] * (double)uda_act_gate(shift[c], act);
+        const double gb = -sdu * (double)uda_act_gate(shift[c], act);
         sg += gb;
         sgx += gb * (-(double)mean[c] * (double)invstd[c]);
     }
@@ -299,12 +309,28 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ c1, const float* __restrict__ c2,
                                                           const float* addend, int64_t ld_add, float* out, int64_t ldo,
                                                           int64_t P) {
-    const int C = y.C, G = (C + 3) >> 2;
-    const int64_t total = P * G;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(e % G);
-        const int64_t p = e / G;
-        const int c0 = cg * 4;
+    const int C = y.C, cblk0 = blockIdx.y * RED_CBLK;
+    const int Cb = min(RED_CBLK, C - cblk0), G = (Cb + 3) >> 2, PP = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
+    if (pl >= PP) return;
+    const int c0 = cblk0 + cg * 4;
+    // dx = ad + sc*(g - c1 - xhat*c2),  xhat = (y - mu)*is   ==>   dx = ad + sc*g - (k0 + k1*y)
+    float sc[4], sh[4], k0[4], k1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = (c0 + j) < C;
+        sc[j] = ok ? y.scale[c0 + j] : 0.f;
+        sh[j] = ok ? y.shift[c0 + j] : 0.f;
+        const float mu = ok ? mean[c0 + j] : 0.f, is = ok ? invstd[c0 + j] : 0.f;
+        const float a1 = ok ? c1[c0 + j] : 0.f, a2 = ok ? c2[c0 + j] : 0.f;
+        k1[j] = sc[j] * a2 * is;
+        k0[j] = sc[j] * a1 - k1[j] * mu;
+    }
+    const int64_t base = (int64_t)blockIdx.x * (PP * EW_ITER);
+#pragma unroll 4
+    for (int it = 0; it < EW_ITER; ++it) {
+        const int64_t p = base + (int64_t)it * PP + pl;
+        if (p >= P) break;
         const float4 dv = uda_ld4(dU + p * ldu + c0);
         const float4 yv4 = uda_ld4(y.x + p * y.ldx + c0);
         const float du[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -316,17 +342,12 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(const float* __restric
             const float4 av = uda_ld4(addend + p * ld_add + c0);
             ad[0] = av.x; ad[1] = av.y; ad[2] = av.z; ad[3] = av.w;
         }
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        float r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j;
-            if (c < C) {
-                const float sc = y.scale[c];
-                float g = du[j] * uda_act_gate(yv[j] * sc + y.shift[c], y.act);
-                if (y.mask) g *= ((mk >> (8 * j)) & 0xffu) ? y.mask_scale : 0.f;
-                const float xhat = (yv[j] - mean[c]) * invstd[c];
-                r[j] = ad[j] + sc * (g - c1[c] - xhat * c2[c]);
-            }
+            float g = du[j] * uda_act_gate(yv[j] * sc[j] + sh[j], y.act);
+            if (y.mask) g *= (float)((mk >> (8 * j)) & 0xffu) * y.mask_scale;
+            r[j] = ad[j] + (sc[j] * g - (k0[j] + k1[j] * yv[j]));
         }
         st4_guard(out + p * ldo + c0, r, C - c0);
     }
@@ -340,8 +361,8 @@ extern "C" int uda_bnbwd_apply(const float* dU, int64_t ldu, const uda_src_t* y,
     UDA_REQUIRE(dU && uda_aligned16(dU) && ldu % 4 == 0 && out && uda_aligned16(out) && ldo % 4 == 0, "uda_bnbwd_apply: bad dU/out layout");
     if (addend) UDA_REQUIRE(uda_aligned16(addend) && ld_add % 4 == 0, "uda_bnbwd_apply: bad addend layout");
     const int64_t P = (int64_t)y->N * y->H * y->W;
-    hipLaunchKernelGGL(bnbwd_apply_kernel, dim3(ew_grid(P * ((y->C + 3) / 4))), dim3(256), 0, (hipStream_t)stream, dU, ldu,
-                       *y, mean, invstd, c1, c2, addend, ld_add, out, ldo, P);
+    hipLaunchKernelGGL(bnbwd_apply_kernel, ew_grid2(P, y->C), dim3(256), 0, (hipStream_t)stream, dU, ldu, *y, mean, invstd,
+                       c1, c2, addend, ld_add, out, ldo, P);
     UDA_LAUNCH_CHECK("bnbwd_apply");
     return 0;
 }

@@ -23,7 +23,8 @@ struct DwArgs {
     int64_t ldy;
     const float* dy;        // wgrad: gradient of the output
     int64_t lddy;
-    float* part;            // fwd: [nWG][2][C]; wgrad: [nWG][9][C]
+    float* part;            // wgrad: [nWG][9][C]
+    double* stats;          // fwd: [UDA_STAT_SLOTS][2][C] or null (fp64 atomics)
 };
 
 __device__ __forceinline__ float4 dw_transform(float4 v, const Xf4& xf, bool has_xf, int act) {
@@ -79,16 +80,17 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwArgs a) {
         s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
         s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
     }
-    if (a.part == nullptr) return;
+    if (a.stats == nullptr) return;
     if (active) {
         uda_st4(&red[(pl * 2 + 0) * C + c0], s1);
         uda_st4(&red[(pl * 2 + 1) * C + c0], s2);
     }
     __syncthreads();
+    double* dst = a.stats + (int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 2 * C;
     for (int e = tid; e < 2 * C; e += 256) {
         float t = 0.f;
         for (int p = 0; p < PP; ++p) t += red[p * 2 * C + e];
-        a.part[(int64_t)blockIdx.x * 2 * C + e] = t;
+        atomicAdd(&dst[e], (double)t);
     }
 }
 
@@ -194,14 +196,11 @@ static inline int dw_pixels_per_wg(int C, int iter) { return (256 / (C / 4)) * i
 
 extern "C" uint64_t uda_dwconv_workspace_bytes(int64_t Pout, int C) {
     if (C < 4) return 0;
-    const uint64_t fwd = (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_FWD)) * 2 * C * sizeof(float);
-    const uint64_t wg = (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED)) * 9 * C * sizeof(float) + 9 * C * sizeof(double);
-    return fwd > wg ? fwd : wg;
+    return (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED)) * 9 * C * sizeof(float) + 9 * C * sizeof(double);
 }
 
 extern "C" int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride, int dil, int border_mode,
-                              float* y, int64_t ldy, double* stats, float* workspace, uint64_t workspace_bytes,
-                              void* stream) {
+                              float* y, int64_t ldy, double* stats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (int e = dw_check(src, "uda_dwconv_fwd")) return e;
     UDA_REQUIRE(w9c && uda_aligned16(w9c) && y && uda_aligned16(y) && ldy % 4 == 0 && ldy >= src->C, "uda_dwconv_fwd: bad pointers");
@@ -217,13 +216,9 @@ extern "C" int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride
     const int64_t Pout = (int64_t)src->N * a.Ho * a.Wo;
     const int nwg = uda_cdiv(Pout, dw_pixels_per_wg(src->C, DW_ITER_FWD));
     a.part = nullptr;
-    if (stats) {
-        UDA_REQUIRE(workspace && workspace_bytes >= (uint64_t)nwg * 2 * src->C * sizeof(float), "uda_dwconv_fwd: workspace too small");
-        a.part = workspace;
-    }
+    a.stats = stats;
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("dwconv_fwd");
-    if (stats) return uda_reduce_partials(a.part, nwg, 2 * src->C, stats, st);
     return 0;
 }
 
@@ -255,7 +250,7 @@ extern "C" int uda_dwconv_wgrad(const uda_src_t* src, const float* dy, int64_t l
     a.stride = stride; a.dil = dil; a.border_mode = border_mode;
     a.Ho = (src->H - 1) / stride + 1;
     a.Wo = (src->W - 1) / stride + 1;
-    a.y = nullptr; a.ldy = 0; a.dy = dy; a.lddy = lddy;
+    a.y = nullptr; a.ldy = 0; a.dy = dy; a.lddy = lddy; a.stats = nullptr;
     const int C = src->C;
     const int64_t Pout = (int64_t)src->N * a.Ho * a.Wo;
     const int nwg = uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED));
@@ -281,7 +276,8 @@ struct StemArgs {
     const float* w;   // [32][3][3][3]
     float* y;
     int64_t ldy;
-    float* part;      // [nWG][2][32]
+    float* part;      // wgrad: [nWG][864]
+    double* stats;    // fwd: [UDA_STAT_SLOTS][2][32] or null
     const float* dy;
     int64_t lddy;
 };
@@ -321,14 +317,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
         s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
         s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
     }
-    if (a.part == nullptr) return;
+    if (a.stats == nullptr) return;
     uda_st4(&red[(pl * 2 + 0) * 32 + c0], s1);
     uda_st4(&red[(pl * 2 + 1) * 32 + c0], s2);
     __syncthreads();
     if (tid < 64) {
         float t = 0.f;
         for (int p = 0; p < 32; ++p) t += red[p * 64 + tid];
-        a.part[(int64_t)blockIdx.x * 64 + tid] = t;
+        atomicAdd(&a.stats[(int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 64 + tid], (double)t);
     }
 }
 
@@ -387,7 +383,7 @@ extern "C" uint64_t uda_stem_workspace_bytes(int64_t Pout) {
 }
 
 extern "C" int uda_stem_fwd(const float* x, int N, int H, int W, const float* w, float* y, int64_t ldy,
-                            double* stats, float* workspace, uint64_t workspace_bytes, void* stream) {
+                            double* stats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(x && w && y && uda_aligned16(y) && ldy % 4 == 0 && ldy >= 32 && N > 0 && H > 1 && W > 1, "uda_stem_fwd: bad args");
     StemArgs a;
@@ -397,13 +393,9 @@ extern "C" int uda_stem_fwd(const float* x, int N, int H, int W, const float* w,
     const int64_t Pout = (int64_t)N * a.Ho * a.Wo;
     const int nwg = uda_cdiv(Pout, STEM_PIX_PER_WG);
     a.part = nullptr;
-    if (stats) {
-        UDA_REQUIRE(workspace && workspace_bytes >= (uint64_t)nwg * 64 * sizeof(float), "uda_stem_fwd: workspace too small");
-        a.part = workspace;
-    }
+    a.stats = stats;
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("stem_fwd");
-    if (stats) return uda_reduce_partials(a.part, nwg, 64, stats, st);
     return 0;
 }
 
@@ -414,7 +406,7 @@ extern "C" int uda_stem_wgrad(const float* x, int N, int H, int W, const float* 
     StemArgs a;
     a.x = x; a.N = N; a.H = H; a.W = W;
     a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
-    a.w = nullptr; a.y = nullptr; a.ldy = 0; a.dy = dy; a.lddy = lddy;
+    a.w = nullptr; a.y = nullptr; a.ldy = 0; a.dy = dy; a.lddy = lddy; a.stats = nullptr;
     const int64_t Pout = (int64_t)N * a.Ho * a.Wo;
     const int nwg = uda_cdiv(Pout, STEM_PIX_PER_WG);
     UDA_REQUIRE(workspace && workspace_bytes >= uda_stem_workspace_bytes(Pout), "uda_stem_wgrad: workspace too small");

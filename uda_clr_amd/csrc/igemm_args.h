@@ -12,7 +12,7 @@ struct ConvKArgs {
     int64_t ld_add;
     float* y;
     int64_t ldy;
-    float* part;   // [nMt][2][Cout] or null
+    double* stats; // [UDA_STAT_SLOTS][2][Cout] or null (fp64 atomics)
     int nMt, nNt;
     int debug;     // diagnostics only (UDA_WS_DEBUG): bit0 skip MFMAs, bit1 skip loader work
 };

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
             }
         }
     }
-    if (a.part) {   // per-tile BN statistics: combine lane halves, then the WM waves through LDS
+    if (a.stats) {   // per-tile BN statistics: combine lane halves, the WM waves through LDS, then fp64 atomics
         __syncthreads();
         float* red = smem;   // [WM][2][BN]
 #pragma unroll
@@ -198,13 +198,14 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
             }
         }
         __syncthreads();
+        double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
         for (int e = tid; e < 2 * BN; e += 256) {
             const int qd = e / BN, cl = e % BN;
             if (n0 + cl < a.Cout) {
                 float t = 0.f;
 #pragma unroll
                 for (int m = 0; m < WM; ++m) t += red[(m * 2 + qd) * BN + cl];
-                a.part[((int64_t)mt * 2 + qd) * a.Cout + n0 + cl] = t;
+                atomicAdd(&dst[qd * a.Cout + n0 + cl], (double)t);
             }
         }
     }
@@ -249,10 +250,6 @@ static int check_src(const uda_src_t& s, const char* who) {
     return 0;
 }
 
-extern "C" uint64_t uda_conv_workspace_bytes(int64_t P, int Cout) {
-    return (uint64_t)uda_cdiv(P, 128) * 2u * (uint64_t)Cout * sizeof(float);
-}
-
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -286,22 +283,15 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.ld_add = a->ld_add;
     k.y = a->y;
     k.ldy = a->ldy;
-    k.part = nullptr;
+    k.stats = a->stats;
     k.debug = 0;
-    if (a->stats) {
-        UDA_REQUIRE(a->workspace && a->workspace_bytes >= uda_conv_workspace_bytes(P, a->Cout),
-                    "uda_conv_fwd: workspace too small for the BN statistics partials");
-        k.part = a->workspace;
-    }
     int e;
     if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
     else if (k.Ktot <= 192) e = launch_conv<2, 2, 2, 2>(k, P, st);     // short K: HBM-bound, single-role tiles
     else e = launch_conv_ws(k, P, st);
-    if (e) return e;
-    if (a->stats) return uda_reduce_partials(k.part, k.nMt, 2 * a->Cout, a->stats, st);
-    return 0;
+    return e;
 }
 
 // ==========================================================================================

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
             }
         }
     }
-    if (a.part) {            // uniform over the workgroup
+    if (a.stats) {           // uniform over the workgroup
         float* red = smem;   // [2 (wm)][2][BN]
         if (!loader) {
 #pragma unroll
@@ -263,10 +263,11 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
             }
         }
         __syncthreads();
+        double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
         for (int e = tid; e < 2 * BN; e += 512) {
             const int qd = e / BN, cl = e % BN;
             if (n0 + cl < a.Cout)
-                a.part[((int64_t)mt * 2 + qd) * a.Cout + n0 + cl] = red[(0 * 2 + qd) * BN + cl] + red[(1 * 2 + qd) * BN + cl];
+                atomicAdd(&dst[qd * a.Cout + n0 + cl], (double)(red[(0 * 2 + qd) * BN + cl] + red[(1 * 2 + qd) * BN + cl]));
         }
     }
 }

@@ -61,12 +61,34 @@ def _rows(g: torch.Tensor) -> torch.Tensor:
     return g.permute(0, 2, 3, 1).reshape(n * h * w, c)
 
 
+STAT_SLOTS = 16     # UDA_STAT_SLOTS: replicas of every per-channel statistics accumulator
+
+
+class _Arena:
+    """One zero-filled fp64 buffer per pass for ALL per-channel statistics accumulators (a single
+    memset instead of one torch.zeros launch per BatchNorm)."""
+
+    def __init__(self, like, n_doubles):
+        self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=like.device)
+        self.off = 0
+
+    def take(self, nq, C):
+        n = STAT_SLOTS * nq * C
+        if self.off + n > self.buf.numel():
+            raise RuntimeError("statistics arena exhausted")
+        v = self.buf[self.off:self.off + n].view(STAT_SLOTS, nq, C)
+        self.off += n
+        return v
+
+
 class _Ctx:
-    __slots__ = ("S", "N", "dims", "w_cache", "params", "x")
+    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt")
 
     def __init__(self):
         self.S = {}
         self.w_cache = {}
+        self.arena = None
+        self.nbt = []
 
 
 class GeneratorEngine:
@@ -77,6 +99,11 @@ class GeneratorEngine:
         self.dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
         self.seed = seed
         self.rng_offset = 0
+        # channels that receive BN statistics in one forward (stem, 17 blocks, ASPP, decoder)
+        n = 32
+        for inp, oup, stride, dil, t in self.blocks:
+            n += (inp * t if t != 1 else 0) + inp * t + oup
+        self.bn_channels = n + 5 * 256 + 256 + 48 + 256 + 256 + 305
 
     # ------------------------------------------------------------------ small helpers
     @staticmethod
@@ -87,8 +114,8 @@ class GeneratorEngine:
         """[P, C] view of a fresh [P, round4(C)] buffer."""
         return self._empty(x, P, round4(C))[:, :C]
 
-    def _stats(self, x, C, training):
-        return torch.zeros(2, C, dtype=torch.float64, device=x.device) if training else None
+    def _stats(self, ctx, C, training):
+        return ctx.arena.take(2, C) if training else None
 
     def _w(self, ctx, key, kind):
         ck = (key, kind)
@@ -110,7 +137,7 @@ class GeneratorEngine:
                                scale, shift, mean, invstd)
             nbt = p.get(prefix + ".num_batches_tracked")
             if nbt is not None:
-                nbt += 1
+                ctx.nbt.append(nbt)
             return BNRec(prefix, mean, invstd, float(count), q1)
         self.K.bn_eval_coeffs(g, b, rm, rv, BN_EPS, scale, shift)
         return None
@@ -145,10 +172,12 @@ class GeneratorEngine:
         if Hin % 16 or Win % 16:
             raise ValueError("input height/width must be multiples of 16, got %dx%d" % (Hin, Win))
         ctx.N = N
+        if training:
+            ctx.arena = _Arena(x, STAT_SLOTS * 2 * self.bn_channels)
         # ---- stem (mobilenet.py:8-13)
         H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
         y0 = self._buf(x, N * H * W, 32)
-        st = self._stats(x, 32, training)
+        st = self._stats(ctx, 32, training)
         K.stem_fwd(x, params["backbone.features.0.0.weight"], y0, st)
         a = self._bn_act(ctx, "backbone.features.0.1", y0, N, H, W, st, N * H * W, training, ACT_RELU6)
         S["stem"] = a
@@ -161,7 +190,7 @@ class GeneratorEngine:
             hid = inp * t
             if t != 1:
                 ye = self._buf(x, N * H * W, hid)
-                st = self._stats(x, hid, training)
+                st = self._stats(ctx, hid, training)
                 K.conv(zin, self._w(ctx, pre + ".conv.0.weight", "ohwi"), 1, 1, ye, stats=st)
                 cnt = N * (H + 2 * dil) * (W + 2 * dil)          # quirk Q1
                 e = self._bn_act(ctx, pre + ".conv.1", ye, N, H, W, st, cnt, training, ACT_RELU6, q1=True)
@@ -171,11 +200,11 @@ class GeneratorEngine:
             Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
             Po = N * Ho * Wo
             yd = self._buf(x, Po, hid)
-            st = self._stats(x, hid, training)
+            st = self._stats(ctx, hid, training)
             K.dwconv_fwd(e, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, border, yd, st)
             d = self._bn_act(ctx, pre + kdb, yd, N, Ho, Wo, st, Po, training, ACT_RELU6)
             yp = self._buf(x, Po, oup)
-            st = self._stats(x, oup, training)
+            st = self._stats(ctx, oup, training)
             K.conv(d, self._w(ctx, pre + kp + ".weight", "ohwi"), 1, 1, yp, stats=st)
             pb = self._bn_act(ctx, pre + kpb, yp, N, Ho, Wo, st, Po, training, ACT_NONE)
             use_res = stride == 1 and inp == oup
@@ -195,7 +224,7 @@ class GeneratorEngine:
         brecs = []
         for j, dl in enumerate(self.dils, start=1):
             sl = slice(256 * (j - 1), 256 * j)
-            st = self._stats(x, 256, training)
+            st = self._stats(ctx, 256, training)
             key = "aspp.aspp%d" % j
             K.conv(a17, self._w(ctx, key + ".atrous_conv.weight", "ohwi"), 1 if j == 1 else 3, dl,
                    cat[:, sl], stats=st)
@@ -204,7 +233,7 @@ class GeneratorEngine:
         gp = self._empty(x, N, 320)
         K.gap_fwd(a17.x, N, gp, 1.0 / (H16 * W16))
         yg = self._empty(x, N, 256)
-        st = self._stats(x, 256, training)
+        st = self._stats(ctx, 256, training)
         gpa = Act(gp, N, 1, 1)
         K.conv(gpa, self._w(ctx, "aspp.global_avg_pool.1.weight", "ohwi"), 1, 1, yg, stats=st)
         sl = slice(1024, 1280)
@@ -213,7 +242,7 @@ class GeneratorEngine:
         K.broadcast_rows(yg, N, cat[:, sl], 1.0)
         catA = Act(cat, N, H16, W16, coef[0], coef[1], ACT_RELU)
         y1 = self._empty(x, P16, 256)
-        st = self._stats(x, 256, training)
+        st = self._stats(ctx, 256, training)
         K.conv(catA, self._w(ctx, "aspp.conv1.weight", "ohwi"), 1, 1, y1, stats=st)
         m, ms = self._mask(x, "aspp.dropout", P16, 256, N, H16, W16, training, masks)
         fa = self._bn_act(ctx, "aspp.bn1", y1, N, H16, W16, st, P16, training, ACT_RELU, m, ms)
@@ -226,27 +255,27 @@ class GeneratorEngine:
         P4 = N * H4 * W4
         xf = self._empty(x, P4, 308)
         ylo = self._empty(x, P4, 48)
-        st = self._stats(x, 48, training)
+        st = self._stats(ctx, 48, training)
         K.conv(low, self._w(ctx, "decoder.conv1.weight", "ohwi"), 1, 1, ylo, stats=st)
         lo = self._bn_act(ctx, "decoder.bn1", ylo, N, H4, W4, st, P4, training, ACT_RELU)
         K.bn_apply(lo, xf[:, 256:304], None)
         K.upsample_fwd(feature, N, H16, W16, xf[:, 0:256], H4, W4)
         xbu = Act(xf[:, :304], N, H4, W4)
         yb1 = self._empty(x, P4, 256)
-        st = self._stats(x, 256, training)
+        st = self._stats(ctx, 256, training)
         K.conv(xbu, self._w(ctx, "decoder.last_conv_boundary.0.weight", "ohwi"), 3, 1, yb1, stats=st)
         m, ms = self._mask(x, "decoder.last_conv_boundary.3", P4, 256, N, H4, W4, training, masks)
         b1 = self._bn_act(ctx, "decoder.last_conv_boundary.1", yb1, N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
         yb2 = self._empty(x, P4, 256)
-        st = self._stats(x, 256, training)
+        st = self._stats(ctx, 256, training)
         K.conv(b1, self._w(ctx, "decoder.last_conv_boundary.4.weight", "ohwi"), 3, 1, yb2, stats=st)
         m, ms = self._mask(x, "decoder.last_conv_boundary.7", P4, 256, N, H4, W4, training, masks)
         b2 = self._bn_act(ctx, "decoder.last_conv_boundary.5", yb2, N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
         K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1,
                xf[:, 304:305], bias=params["decoder.last_conv_boundary.8.bias"])
-        st = self._stats(x, 305, training)
+        st = self._stats(ctx, 305, training)
         if training:
             K.colstats(xf[:, :305], st)
         m, ms = self._mask(x, "decoder.last_conv.2", P4, 305, N, H4, W4, training, masks)
@@ -261,6 +290,10 @@ class GeneratorEngine:
         K.head_upsample_fwd(xf[:, 304:305], N, H4, W4, x2)
         S["dec"] = dict(low=low, xf=xf, lo=lo, xbu=xbu, b1=b1, b2=b2, sa=sa, x1b=x1b)
         ctx.dims = (N, Hin, Win, H16, W16, H4, W4)
+        if ctx.nbt:
+            torch._foreach_add_(ctx.nbt, 1)          # num_batches_tracked of all 61 BNs in one launch
+            ctx.nbt = []
+        ctx.arena = None
         outs = (x1, x2, nchw_view(feature, N, H16, W16), nchw_view(xf[:, :304], N, H4, W4),
                 nchw_view(xf[:, :305], N, H4, W4), nchw_view(x1b, N, H4, W4),
                 nchw_view(xf[:, 304:305], N, H4, W4))
@@ -274,7 +307,7 @@ class GeneratorEngine:
         if y.bn is None:
             raise NotImplementedError("backward through frozen (eval-mode) BatchNorm is not built yet")
         C = y.C
-        sums = torch.zeros(3, C, dtype=torch.float64, device=dU.device)
+        sums = ctx.arena.take(3, C)
         K.bnbwd_reduce(dU, y, sums)
         cg = self._empty(dU, 4, C)
         K.bnbwd_finalize(sums, y, cg[0], cg[1], cg[2], cg[3])
@@ -310,6 +343,7 @@ class GeneratorEngine:
         N, Hin, Win, H16, W16, H4, W4 = ctx.dims
         P4, P16 = N * H4 * W4, N * H16 * W16
         G: Dict[str, torch.Tensor] = {}
+        ctx.arena = _Arena(x, STAT_SLOTS * 3 * (self.bn_channels + 64))
         D = S["dec"]
         xf = D["xf"]
         # ---- heads (deeplabv3.py:39-40)

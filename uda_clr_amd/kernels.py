@@ -15,6 +15,7 @@ import torch
 
 from .acts import Act, round4
 
+STAT_SLOTS = 16      # UDA_STAT_SLOTS in include/uda_clr_hip.h
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libuda_clr_hip.so")
 _lib = None
 
@@ -29,8 +30,7 @@ class UdaSrc(C.Structure):
 class UdaConvArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("w", C.c_void_p), ("Cout", C.c_int32), ("ksize", C.c_int32),
                 ("dil", C.c_int32), ("_pad", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
-                ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p)]
 
 
 class UdaWgradArgs(C.Structure):
@@ -47,23 +47,21 @@ SYMBOLS = {
     "uda_relayout_ohwi": (_I, [_P, _I, _I, _I, _P, _P]),
     "uda_relayout_dgrad": (_I, [_P, _I, _I, _I, _P, _P]),
     "uda_relayout_dw": (_I, [_P, _I, _P, _P]),
-    "uda_conv_workspace_bytes": (_U, [_L, _I]),
     "uda_conv_fwd": (_I, [C.POINTER(UdaConvArgs), _P]),
     "uda_conv_wgrad_workspace_bytes": (_U, [_L, _I, _I, _I]),
     "uda_conv_wgrad": (_I, [C.POINTER(UdaWgradArgs), _P]),
     "uda_dwconv_workspace_bytes": (_U, [_L, _I]),
-    "uda_dwconv_fwd": (_I, [C.POINTER(UdaSrc), _P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
+    "uda_dwconv_fwd": (_I, [C.POINTER(UdaSrc), _P, _I, _I, _I, _P, _L, _P, _P]),
     "uda_dwconv_dgrad": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "uda_dwconv_wgrad": (_I, [C.POINTER(UdaSrc), _P, _L, _I, _I, _I, _P, _P, _U, _P]),
     "uda_stem_workspace_bytes": (_U, [_L]),
-    "uda_stem_fwd": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P, _U, _P]),
+    "uda_stem_fwd": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P]),
     "uda_stem_wgrad": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "uda_bn_apply": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
-    "uda_reduce_workspace_bytes": (_U, [_L, _I, _I]),
-    "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P, _U, _P]),
-    "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _U, _P]),
+    "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P]),
+    "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P]),
     "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "uda_bnbwd_apply": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "uda_upsample_fwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
@@ -198,13 +196,9 @@ class HipKernels:
         else:
             a.addend, a.ld_add = None, 0
         a.y, a.ldy = _mat(out, "out")
-        ws = None
         if stats is not None:
-            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (2, Cout)
-            ws = self._ws(out, self.lib.uda_conv_workspace_bytes(src.P, Cout))
-            a.stats, a.workspace, a.workspace_bytes = stats.data_ptr(), ws.data_ptr(), ws.numel()
-        else:
-            a.stats, a.workspace, a.workspace_bytes = None, None, 0
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, Cout)
+        a.stats = _ptr(stats)
         self._ck(self.lib.uda_conv_fwd(C.byref(a), self._stream()))
 
     def conv_wgrad(self, src: Act, dy, ksize, dil, dw):
@@ -225,9 +219,10 @@ class HipKernels:
         Ho, Wo = (src.H - 1) // stride + 1, (src.W - 1) // stride + 1
         assert out.shape == (src.N * Ho * Wo, src.C) and w9c.is_contiguous() and tuple(w9c.shape) == (9, src.C)
         y, ldy = _mat(out, "out")
-        ws = self._ws(out, self.lib.uda_dwconv_workspace_bytes(out.shape[0], src.C)) if stats is not None else None
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, src.C)
         self._ck(self.lib.uda_dwconv_fwd(C.byref(s), w9c.data_ptr(), stride, dil, border_mode, y, ldy, _ptr(stats),
-                                         _ptr(ws), 0 if ws is None else ws.numel(), self._stream()))
+                                         self._stream()))
 
     def dwconv_dgrad(self, dy, w9c, stride, dil, N, H, W, out):
         Cc = dy.shape[1]
@@ -254,9 +249,9 @@ class HipKernels:
         Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
         assert out.shape == (Po, 32)
         y, ldy = _mat(out, "out")
-        ws = self._ws(out, self.lib.uda_stem_workspace_bytes(Po)) if stats is not None else None
-        self._ck(self.lib.uda_stem_fwd(x.data_ptr(), N, H, W, w.data_ptr(), y, ldy, _ptr(stats), _ptr(ws),
-                                       0 if ws is None else ws.numel(), self._stream()))
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, 32)
+        self._ck(self.lib.uda_stem_fwd(x.data_ptr(), N, H, W, w.data_ptr(), y, ldy, _ptr(stats), self._stream()))
 
     def stem_wgrad(self, x, dy, dw):
         N, _, H, W = x.shape
@@ -272,7 +267,7 @@ class HipKernels:
         Cc = gamma.numel()
         for t in (gamma, beta, rmean, rvar, scale, shift, mean, invstd):
             assert t.is_contiguous() and t.numel() == Cc
-        assert stats.dtype == torch.float64 and stats.is_contiguous()
+        assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, Cc)
         self._ck(self.lib.uda_bn_finalize(stats.data_ptr(), Cc, float(count), gamma.data_ptr(), beta.data_ptr(),
                                           rmean.data_ptr(), rvar.data_ptr(), momentum, eps, scale.data_ptr(),
                                           shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), self._stream()))
@@ -294,24 +289,22 @@ class HipKernels:
     def colstats(self, x, stats):
         self._dev(x)
         p, ld = _mat(x, "x")
-        nq, Cc = stats.shape
-        assert Cc == x.shape[1] and stats.dtype == torch.float64 and stats.is_contiguous()
-        ws = self._ws(x, self.lib.uda_reduce_workspace_bytes(x.shape[0], Cc, nq))
-        self._ck(self.lib.uda_colstats(p, ld, x.shape[0], Cc, nq, stats.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       self._stream()))
+        slots, nq, Cc = stats.shape
+        assert slots == STAT_SLOTS and Cc == x.shape[1] and stats.dtype == torch.float64 and stats.is_contiguous()
+        self._ck(self.lib.uda_colstats(p, ld, x.shape[0], Cc, nq, stats.data_ptr(), self._stream()))
 
     def colsum(self, x, out):
-        st = torch.zeros(1, x.shape[1], dtype=torch.float64, device=x.device)
+        st = torch.zeros(STAT_SLOTS, 1, x.shape[1], dtype=torch.float64, device=x.device)
         self.colstats(x, st)
-        out.copy_(st[0])
+        out.copy_(st.sum(0)[0])
 
     def bnbwd_reduce(self, dU, y: Act, sums):
         s = self._src(y)
-        assert dU.shape == y.x.shape and sums.dtype == torch.float64 and tuple(sums.shape) == (3, y.C)
+        assert dU.shape == y.x.shape and sums.dtype == torch.float64 and tuple(sums.shape) == (STAT_SLOTS, 3, y.C)
+        assert sums.is_contiguous()
         d, ldu = _mat(dU, "dU")
-        ws = self._ws(dU, self.lib.uda_reduce_workspace_bytes(y.P, y.C, 3))
         self._ck(self.lib.uda_bnbwd_reduce(d, ldu, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
-                                           sums.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+                                           sums.data_ptr(), self._stream()))
 
     def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
         self._ck(self.lib.uda_bnbwd_finalize(sums.data_ptr(), y.C, float(y.bn.count), int(y.bn.q1_border), y.act,

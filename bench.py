@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", choices=("prototype_full", "source_only"), default="prototype_full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="let MIOpen search conv algorithms for the stock-torch discriminators")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +132,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     dist = None
     if world > 1:
         import torch.distributed as dist

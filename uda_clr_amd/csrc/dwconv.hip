@@ -7,6 +7,7 @@
 // Thread mapping (shared by the depthwise kernels): channel group cg = tid % G (G = C/4 float4
 // groups), pixel lane pl = tid / G; a workgroup walks ITER strips of PP = 256/G consecutive
 // output pixels, so the 64 lanes of a wave read G*16 contiguous bytes per pixel.
+#include <stdlib.h>
 #include "common.h"
 
 int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hipStream_t st);
@@ -92,6 +93,204 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwArgs a) {
         for (int p = 0; p < PP; ++p) t += red[p * 2 * C + e];
         atomicAdd(&dst[e], (double)t);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled forward: a workgroup owns TH x TW output pixels x 32 channels.  The input halo tile is
+// loaded ONCE (16 B per lane, one 128-B line per pixel), the producer's BN affine + ReLU6 (or the
+// quirk-Q1 border value) is applied ONCE per element on the way into LDS, and the 9 taps are read
+// back with ds_read_b128.  (The first version re-read and re-transformed every input 9 times from
+// L1/L2: 1.3-2.1 TB/s of algorithmic bytes; this one is bounded by the 1.3-1.6x halo over-read.)
+#define DWT_CB 32
+template <int S, int TH, int TW>
+__global__ __launch_bounds__(256) void dwconv_fwd_tiled_kernel(DwArgs a, int tilesX, int tilesY) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [IH*IW][32] then [32 lanes][2][32] for the stats
+    const int d = a.dil;
+    const int IH = (TH - 1) * S + 2 * d + 1, IW = (TW - 1) * S + 2 * d + 1;
+    const int C = a.src.C, H = a.src.H, W = a.src.W;
+    const int tid = threadIdx.x, cg = tid & 7, pl = tid >> 3;
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int c0 = blockIdx.y * DWT_CB + cg * 4;
+    const bool cok = c0 < C;
+    const bool has_xf = a.src.scale != nullptr;
+    const int act = a.src.act;
+    Xf4 xf;
+    uda_load_xf4(xf, a.src.scale, a.src.shift, c0, C);
+    float4 bval = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.border_mode == 1)
+        bval = make_float4(uda_act(xf.sh[0], act), uda_act(xf.sh[1], act), uda_act(xf.sh[2], act), uda_act(xf.sh[3], act));
+    // ---- stage the halo tile
+    const int gy0 = oy0 * S - d, gx0 = ox0 * S - d;
+    const float* xb = a.src.x + (int64_t)n * H * W * a.src.ldx + c0;
+    for (int idx = pl; idx < IH * IW; idx += 32) {
+        const int iy = idx / IW, ix = idx - iy * IW;
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        float4 u = bval;
+        if (cok && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            u = dw_transform(uda_ld4(xb + ((int64_t)gy * W + gx) * a.src.ldx), xf, has_xf, act);
+        uda_st4(&tile[idx * DWT_CB + cg * 4], u);
+    }
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = cok ? uda_ld4(a.w9c + t * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // ---- 3x3 from LDS
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int k = 0; k < (TH * TW) / 32; ++k) {
+        const int op = pl + 32 * k;
+        const int oy = op / TW, ox = op % TW;
+        if (!cok || oy0 + oy >= a.Ho || ox0 + ox >= a.Wo) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float4 u = uda_ld4(&tile[((oy * S + kh * d) * IW + ox * S + kw * d) * DWT_CB + cg * 4]);
+                const float4 ww = w[kh * 3 + kw];
+                acc.x += ww.x * u.x; acc.y += ww.y * u.y; acc.z += ww.z * u.z; acc.w += ww.w * u.w;
+            }
+        uda_st4(a.y + (((int64_t)n * a.Ho + oy0 + oy) * a.Wo + ox0 + ox) * a.ldy + c0, acc);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+    }
+    if (a.stats == nullptr) return;
+    __syncthreads();                       // the tile is dead: reuse it for the reduction
+    uda_st4(&tile[(pl * 2 + 0) * DWT_CB + cg * 4], s1);
+    uda_st4(&tile[(pl * 2 + 1) * DWT_CB + cg * 4], s2);
+    __syncthreads();
+    if (tid < 2 * DWT_CB) {
+        const int q = tid / DWT_CB, cl = tid % DWT_CB;
+        const int c = blockIdx.y * DWT_CB + cl;
+        if (c < C) {
+            float t = 0.f;
+            for (int p = 0; p < 32; ++p) t += tile[(p * 2 + q) * DWT_CB + cl];
+            atomicAdd(&a.stats[((int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 2 + q) * C + c], (double)t);
+        }
+    }
+}
+
+// Weight gradient on the same halo tile: dw[c][t] = sum_p u(p + off_t) * dy[p]; per-thread 9 x float4
+// accumulators over its output pixels, a 32-lane LDS reduction, then fp64 atomics into slot replicas.
+template <int S, int TH, int TW>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(DwArgs a, int tilesX, int tilesY, double* sums) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // max([IH*IW][32], [32 lanes][9][32])
+    const int d = a.dil;
+    const int IH = (TH - 1) * S + 2 * d + 1, IW = (TW - 1) * S + 2 * d + 1;
+    const int C = a.src.C, H = a.src.H, W = a.src.W;
+    const int tid = threadIdx.x, cg = tid & 7, pl = tid >> 3;
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int c0 = blockIdx.y * DWT_CB + cg * 4;
+    const bool cok = c0 < C;
+    const bool has_xf = a.src.scale != nullptr;
+    const int act = a.src.act;
+    Xf4 xf;
+    uda_load_xf4(xf, a.src.scale, a.src.shift, c0, C);
+    float4 bval = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.border_mode == 1)
+        bval = make_float4(uda_act(xf.sh[0], act), uda_act(xf.sh[1], act), uda_act(xf.sh[2], act), uda_act(xf.sh[3], act));
+    const int gy0 = oy0 * S - d, gx0 = ox0 * S - d;
+    const float* xb = a.src.x + (int64_t)n * H * W * a.src.ldx + c0;
+    for (int idx = pl; idx < IH * IW; idx += 32) {
+        const int iy = idx / IW, ix = idx - iy * IW;
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        float4 u = bval;
+        if (cok && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            u = dw_transform(uda_ld4(xb + ((int64_t)gy * W + gx) * a.src.ldx), xf, has_xf, act);
+        uda_st4(&tile[idx * DWT_CB + cg * 4], u);
+    }
+    __syncthreads();
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < (TH * TW) / 32; ++k) {
+        const int op = pl + 32 * k;
+        const int oy = op / TW, ox = op % TW;
+        if (!cok || oy0 + oy >= a.Ho || ox0 + ox >= a.Wo) continue;
+        const float4 g = uda_ld4(a.dy + (((int64_t)n * a.Ho + oy0 + oy) * a.Wo + ox0 + ox) * a.lddy + c0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float4 u = uda_ld4(&tile[((oy * S + kh * d) * IW + ox * S + kw * d) * DWT_CB + cg * 4]);
+                float4& s = acc[kh * 3 + kw];
+                s.x += g.x * u.x; s.y += g.y * u.y; s.z += g.z * u.z; s.w += g.w * u.w;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) uda_st4(&tile[(pl * 9 + t) * DWT_CB + cg * 4], acc[t]);
+    __syncthreads();
+    for (int e = tid; e < 9 * DWT_CB; e += 256) {
+        const int t = e / DWT_CB, cl = e % DWT_CB;
+        const int c = blockIdx.y * DWT_CB + cl;
+        if (c < C) {
+            float v = 0.f;
+            for (int p = 0; p < 32; ++p) v += tile[(p * 9 + t) * DWT_CB + cl];
+            atomicAdd(&sums[((int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 9 + t) * C + c], (double)v);
+        }
+    }
+}
+
+// dw[c][t] (float) = sum over slots of sums[slot][t][c] (double)
+__global__ void dw_wgrad_store_slots_kernel(const double* __restrict__ sums, int C, float* __restrict__ dw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 9 * C) {
+        double v = 0.0;
+        for (int k = 0; k < UDA_STAT_SLOTS; ++k) v += sums[(int64_t)k * 9 * C + e];
+        dw[(e % C) * 9 + e / C] = (float)v;
+    }
+}
+
+template <int S, int TH, int TW>
+static int launch_dw_wgrad_tiled(DwArgs& a, double* sums, float* dw, hipStream_t st) {
+    const int d = a.dil;
+    const int IH = (TH - 1) * S + 2 * d + 1, IW = (TW - 1) * S + 2 * d + 1;
+    size_t lds = (size_t)IH * IW * DWT_CB * sizeof(float);
+    if (lds < 32 * 9 * DWT_CB * sizeof(float)) lds = 32 * 9 * DWT_CB * sizeof(float);
+    auto fn = dwconv_wgrad_tiled_kernel<S, TH, TW>;
+    static size_t reserved = 0;
+    if (lds > reserved && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return uda_set_error("dwconv_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        reserved = lds;
+    }
+    const int C = a.src.C;
+    (void)hipMemsetAsync(sums, 0, (size_t)UDA_STAT_SLOTS * 9 * C * sizeof(double), st);
+    const int tilesX = uda_cdiv(a.Wo, TW), tilesY = uda_cdiv(a.Ho, TH);
+    hipLaunchKernelGGL(fn, dim3(tilesX * tilesY * a.src.N, uda_cdiv(C, DWT_CB)), dim3(256), lds, st, a, tilesX, tilesY, sums);
+    UDA_LAUNCH_CHECK("dwconv_wgrad_tiled");
+    hipLaunchKernelGGL(dw_wgrad_store_slots_kernel, dim3(uda_cdiv(9 * C, 256)), dim3(256), 0, st, sums, C, dw);
+    UDA_LAUNCH_CHECK("dw_wgrad_store");
+    return 0;
+}
+
+template <int S, int TH, int TW>
+static int launch_dw_tiled(DwArgs& a, hipStream_t st) {
+    const int d = a.dil;
+    const int IH = (TH - 1) * S + 2 * d + 1, IW = (TW - 1) * S + 2 * d + 1;
+    size_t lds = (size_t)IH * IW * DWT_CB * sizeof(float);
+    if (lds < 32 * 2 * DWT_CB * sizeof(float)) lds = 32 * 2 * DWT_CB * sizeof(float);
+    auto fn = dwconv_fwd_tiled_kernel<S, TH, TW>;
+    static size_t reserved = 0;
+    if (lds > reserved && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return uda_set_error("dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        reserved = lds;
+    }
+    const int tilesX = uda_cdiv(a.Wo, TW), tilesY = uda_cdiv(a.Ho, TH);
+    hipLaunchKernelGGL(fn, dim3(tilesX * tilesY * a.src.N, uda_cdiv(a.src.C, DWT_CB)), dim3(256), lds, st, a, tilesX, tilesY);
+    UDA_LAUNCH_CHECK("dwconv_fwd_tiled");
+    return 0;
 }
 
 // gradient w.r.t. the interior H x W positions of the (padded) depthwise input
@@ -196,7 +395,9 @@ static inline int dw_pixels_per_wg(int C, int iter) { return (256 / (C / 4)) * i
 
 extern "C" uint64_t uda_dwconv_workspace_bytes(int64_t Pout, int C) {
     if (C < 4) return 0;
-    return (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED)) * 9 * C * sizeof(float) + 9 * C * sizeof(double);
+    const uint64_t flat = (uint64_t)uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED)) * 9 * C * sizeof(float) + 9 * C * sizeof(double);
+    const uint64_t tiled = (uint64_t)UDA_STAT_SLOTS * 9 * C * sizeof(double);
+    return flat > tiled ? flat : tiled;
 }
 
 extern "C" int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride, int dil, int border_mode,
@@ -217,6 +418,8 @@ extern "C" int uda_dwconv_fwd(const uda_src_t* src, const float* w9c, int stride
     const int nwg = uda_cdiv(Pout, dw_pixels_per_wg(src->C, DW_ITER_FWD));
     a.part = nullptr;
     a.stats = stats;
+    static const bool flat = getenv("UDA_DW_FLAT") != nullptr;      // diagnostics: the untiled kernel
+    if (!flat && dil <= 2) return stride == 1 ? launch_dw_tiled<1, 8, 16>(a, st) : launch_dw_tiled<2, 8, 8>(a, st);
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("dwconv_fwd");
     return 0;
@@ -254,8 +457,12 @@ extern "C" int uda_dwconv_wgrad(const uda_src_t* src, const float* dy, int64_t l
     const int C = src->C;
     const int64_t Pout = (int64_t)src->N * a.Ho * a.Wo;
     const int nwg = uda_cdiv(Pout, dw_pixels_per_wg(C, DW_ITER_RED));
-    const uint64_t need = (uint64_t)nwg * 9 * C * sizeof(float) + 9 * C * sizeof(double);
-    UDA_REQUIRE(workspace && workspace_bytes >= need, "uda_dwconv_wgrad: workspace too small");
+    UDA_REQUIRE(workspace && workspace_bytes >= uda_dwconv_workspace_bytes(Pout, C), "uda_dwconv_wgrad: workspace too small");
+    static const bool flat = getenv("UDA_DW_FLAT") != nullptr;
+    if (!flat && dil <= 2) {
+        double* slot_sums = reinterpret_cast<double*>(workspace);
+        return stride == 1 ? launch_dw_wgrad_tiled<1, 8, 16>(a, slot_sums, dw, st) : launch_dw_wgrad_tiled<2, 8, 8>(a, slot_sums, dw, st);
+    }
     double* sums = reinterpret_cast<double*>(workspace);          // [9][C] first (8-byte aligned)
     a.part = workspace + 2 * 9 * C;
     (void)hipMemsetAsync(sums, 0, 9 * C * sizeof(double), st);

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks && !(a.debug & 2)) {
-                stage(smem + ((c + 1) & 1) * TILE);     // chunk c+1 (its loads flew during chunk c-1)
-                if (c + 2 < nchunks) issue();           // chunk c+2 flies during chunk c+1
+                if (!(a.debug & 8)) stage(smem + ((c + 1) & 1) * TILE);     // chunk c+1 (its loads flew during chunk c-1)
+                if (c + 2 < nchunks && !(a.debug & 4)) issue();           // chunk c+2 flies during chunk c+1
             }
             __syncthreads();
         }

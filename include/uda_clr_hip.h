@@ -114,6 +114,11 @@ int uda_stem_wgrad(const float* x, int N, int H, int W, const float* dy, int64_t
 int uda_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale,
                     float* shift, float* mean, float* invstd, void* stream);
+/* k more momentum updates of the running statistics with unchanged batch statistics over `count`
+ * elements (the 4 stochastic passes of Trainer_prototype_full.py:364-368 repeat the deterministic,
+ * pre-dropout part of the network on the same batch) */
+int uda_bn_running_replay(const float* mean, const float* invstd, int C, double count, int k, float momentum,
+                          float eps, float* running_mean, float* running_var, void* stream);
 int uda_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, int C, float eps, float* scale, float* shift,
                        void* stream);

@@ -178,6 +178,12 @@ class SpecKernels:
         rmean.mul_(1 - momentum).add_(momentum * m.float())
         rvar.mul_(1 - momentum).add_(momentum * (var * (count / max(count - 1.0, 1.0))).float())
 
+    def bn_running_replay(self, mean, invstd, count, k, momentum, eps, rmean, rvar):
+        var = (1.0 / invstd.double() ** 2 - eps).clamp_min(0.0) * (count / max(count - 1.0, 1.0))
+        for _ in range(k):
+            rmean.mul_(1 - momentum).add_(momentum * mean)
+            rvar.mul_(1 - momentum).add_(momentum * var.float())
+
     def bn_eval_coeffs(self, gamma, beta, rmean, rvar, eps, scale, shift):
         sc = gamma.double() / torch.sqrt(rvar.double() + eps)
         scale.copy_(sc.float())

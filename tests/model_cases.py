@@ -31,7 +31,9 @@ def l2rel(a, b, trim=0.01):
     if d.numel() > 8:
         k = max(1, int(trim * d.numel()))
         d = torch.sort(d).values[:-k]
-    return d.norm().item() / max(b.norm().item(), 1e-30)
+    # a gradient that is analytically zero (e.g. a BN bias feeding another BN) is pure rounding noise in
+    # every fp32 evaluation: measure it against an absolute floor instead of against ~0
+    return d.norm().item() / max(b.norm().item(), 1e-5)
 
 
 def grad_ok(err_hip, err_fp32_oracle):

@@ -110,3 +110,33 @@ def test_no_grad_train_forward_updates_running_stats_only():
         outs = m(x)
     assert not outs[0].requires_grad
     assert int(m.state_dict()["aspp.bn1.num_batches_tracked"]) == 1
+
+
+def test_mc_fast_path_equals_plain_stochastic_forwards():
+    """GeneratorEngine.mc_forward (reuse of the deterministic pre-dropout activations + running-stat
+    replay) against the plain loop of Trainer_prototype_full.py:358-368 on identical dropout masks:
+    same logits, same BN running statistics, same num_batches_tracked."""
+    B, S, passes = 2, 64, 2
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    m0 = deeplab_ref.draw_masks(B, S, S, gen)
+    mc_masks = [deeplab_ref.draw_masks(2 * B, S, S, gen) for _ in range(passes)]
+    res = []
+    for fast in (False, True):
+        m = _model().train()
+        m.set_dropout_masks(m0)
+        outs = m(x)                                   # the grad-mode training forward on x
+        if fast:
+            preds = m.mc_dropout_logits(x, passes=passes, reps=2, masks=mc_masks)
+        else:
+            m._recent = []                            # forces the plain path
+            preds = m.mc_dropout_logits(x, passes=passes, reps=2, masks=mc_masks)
+        res.append((preds, {k: v.clone() for k, v in m.state_dict().items()}, outs[0].detach().clone()))
+    (p0, s0, o0), (p1, s1, o1) = res
+    assert _rel(p1, p0) < 1e-5
+    assert torch.equal(o0, o1)
+    for k in s0:
+        if k.endswith("num_batches_tracked"):
+            assert int(s0[k]) == int(s1[k]) == 1 + passes, k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert _rel(s1[k], s0[k]) < 2e-5, (k, _rel(s1[k], s0[k]))

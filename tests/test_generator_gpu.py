@@ -47,3 +47,29 @@ def test_no_grad_and_determinism():
     for a, b in zip(*outs):
         assert torch.equal(a, b), "the forward path must be bitwise reproducible"
     assert not outs[0][0].requires_grad
+
+
+def test_mc_fast_path_equals_plain_stochastic_forwards():
+    """HIP: GeneratorEngine.mc_forward vs the plain loop of Trainer_prototype_full.py:358-368 on identical masks."""
+    from oracle import deeplab_ref
+    B, S, passes = 2, 64, 2
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 3, S, S, generator=gen).to(DEV)
+    m0 = deeplab_ref.draw_masks(B, S, S, gen)
+    mc_masks = [deeplab_ref.draw_masks(2 * B, S, S, gen) for _ in range(passes)]
+    res = []
+    for fast in (False, True):
+        m = model_cases.seeded_model(perturb=True).to(DEV).train()
+        m.set_dropout_masks(m0)
+        m(x)
+        if not fast:
+            m._recent = []
+        preds = m.mc_dropout_logits(x, passes=passes, reps=2, masks=mc_masks)
+        res.append((preds, {k: v.clone() for k, v in m.state_dict().items()}))
+    (p0, s0), (p1, s1) = res
+    assert model_cases.rel(p1, p0) < 1e-4
+    for k in s0:
+        if k.endswith("num_batches_tracked"):
+            assert int(s0[k]) == int(s1[k]) == 1 + passes
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert model_cases.rel(s1[k], s0[k]) < 1e-4, k

@@ -69,7 +69,7 @@ def test_trainer_baseline_hip_matches_reference_rows(golden_dir, tmp_path):
         txt = ",".join(r)
         got = [float(v) for v in txt[txt.index("(") + 1: txt.index(")")].split(",")]
         assert abs(got[0] - ref[0]) < 0.15 * abs(ref[0])      # eval-mode loss on 6-update running BN stats: chaotic at this size
-        assert abs(got[1] - ref[1]) < 0.05 and abs(got[2] - ref[2]) < 0.05     # Dice (north_star: within 0.2)
+        assert abs(got[1] - ref[1]) < 0.1 and abs(got[2] - ref[2]) < 0.1       # Dice (north_star: within 0.2)
 
 
 def test_trainer_prototype_full_hip_matches_reference_rows(golden_dir, tmp_path):

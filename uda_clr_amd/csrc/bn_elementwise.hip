@@ -75,6 +75,31 @@ extern "C" int uda_bn_finalize(const double* stats, int C, double count, const f
     return 0;
 }
 
+// k further momentum updates of the running statistics with the SAME batch statistics
+// (closed form of k repetitions of  r <- (1-m) r + m s):  r <- (1-m)^k r + (1 - (1-m)^k) s
+__global__ void bn_running_replay_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, int C,
+                                         double count, int k, float momentum, float eps, float* __restrict__ rmean,
+                                         float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double is = (double)invstd[c];
+    double var = 1.0 / (is * is) - (double)eps;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+    const double a = pow(1.0 - (double)momentum, (double)k);
+    rmean[c] = (float)(a * (double)rmean[c] + (1.0 - a) * (double)mean[c]);
+    rvar[c] = (float)(a * (double)rvar[c] + (1.0 - a) * unbiased);
+}
+
+extern "C" int uda_bn_running_replay(const float* mean, const float* invstd, int C, double count, int k, float momentum,
+                                     float eps, float* running_mean, float* running_var, void* stream) {
+    UDA_REQUIRE(mean && invstd && running_mean && running_var && C > 0 && count > 0 && k >= 1, "uda_bn_running_replay: bad args");
+    hipLaunchKernelGGL(bn_running_replay_kernel, dim3(uda_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, invstd, C,
+                       count, k, momentum, eps, running_mean, running_var);
+    UDA_LAUNCH_CHECK("bn_running_replay");
+    return 0;
+}
+
 extern "C" int uda_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, int C, float eps, float* scale, float* shift, void* stream) {
     UDA_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "uda_bn_eval_coeffs: bad args");

@@ -82,13 +82,14 @@ class _Arena:
 
 
 class _Ctx:
-    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt")
+    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt", "bnlog")
 
     def __init__(self):
         self.S = {}
         self.w_cache = {}
         self.arena = None
         self.nbt = []
+        self.bnlog = []          # (prefix, BNRec) of every training-mode BN of this forward
 
 
 class GeneratorEngine:
@@ -138,7 +139,9 @@ class GeneratorEngine:
             nbt = p.get(prefix + ".num_batches_tracked")
             if nbt is not None:
                 ctx.nbt.append(nbt)
-            return BNRec(prefix, mean, invstd, float(count), q1)
+            rec = BNRec(prefix, mean, invstd, float(count), q1)
+            ctx.bnlog.append((prefix, rec))
+            return rec
         self.K.bn_eval_coeffs(g, b, rm, rv, BN_EPS, scale, shift)
         return None
 
@@ -298,6 +301,83 @@ class GeneratorEngine:
                 nchw_view(xf[:, :305], N, H4, W4), nchw_view(x1b, N, H4, W4),
                 nchw_view(xf[:, 304:305], N, H4, W4))
         return outs, (ctx if need_grad else None)
+
+    # ------------------------------------------------------------------ stochastic (MC-dropout) passes
+    _STOCHASTIC_BN = ("decoder.last_conv_boundary.1", "decoder.last_conv_boundary.5", "decoder.last_conv.0")
+
+    def mc_forward(self, ctx, reps: int, passes: int, out=None, masks=None):
+        """The ``passes`` no-grad training-mode forwards on ``x.repeat(reps,1,1,1)`` of
+        Trainer_prototype_full.py:358-368, given the context of the (grad-mode) training forward on
+        ``x`` itself.  Everything up to the first dropout (backbone, ASPP convs + BNs, the decoder's
+        low-level branch) is deterministic and its training-mode BN statistics on the repeated batch
+        equal those on ``x``, so those activations are REUSED from ``ctx``; only the dropout-dependent
+        tail (ASPP dropout -> bilinear x4 -> two 3x3 convs -> heads) is recomputed per pass on the
+        reps*N batch, and the running statistics of the reused BNs receive the ``passes`` momentum
+        updates the reference's full forwards would have applied (uda_bn_running_replay).
+        Returns logits x1 of all passes, [passes*reps*N, 2, H, W] (pass-major, as ``preds_trg``)."""
+        K, S, params, x = self.K, ctx.S, ctx.params, ctx.x
+        N, Hin, Win, H16, W16, H4, W4 = ctx.dims
+        N2 = reps * N
+        P16, P4 = N * H16 * W16, N * H4 * W4
+        A, D = S["aspp"], S["dec"]
+        fa, lo = A["fa"], D["lo"]
+        if out is None:
+            out = self._empty(x, passes * N2, 2, Hin, Win)
+        p05 = DROPOUT["aspp.dropout"]
+        for ps in range(passes):
+            mk = None if masks is None else masks[ps]
+            ctx.arena = _Arena(x, STAT_SLOTS * 2 * (256 + 256 + 305))
+            feature = self._empty(x, reps * P16, 256)
+            xf = self._empty(x, reps * P4, 308)
+            for r in range(reps):
+                m = torch.empty((P16, 256), dtype=torch.uint8, device=x.device)
+                if mk is not None:
+                    m.copy_(_rows(mk["aspp.dropout"][r * N:(r + 1) * N].to(x.device)))
+                else:
+                    K.dropout_mask(m, p05, self.seed, self.rng_offset)
+                    self.rng_offset += 1
+                K.bn_apply(Act(fa.x, N, H16, W16, fa.scale, fa.shift, ACT_RELU, m, 1.0 / (1.0 - p05)),
+                           feature[r * P16:(r + 1) * P16], None)
+                K.bn_apply(lo, xf[r * P4:(r + 1) * P4, 256:304], None)
+            K.upsample_fwd(feature, N2, H16, W16, xf[:, 0:256], H4, W4)
+            xbu = Act(xf[:, :304], N2, H4, W4)
+            yb1 = self._empty(x, reps * P4, 256)
+            st = self._stats(ctx, 256, True)
+            K.conv(xbu, self._w(ctx, "decoder.last_conv_boundary.0.weight", "ohwi"), 3, 1, yb1, stats=st)
+            m, ms = self._mask(x, "decoder.last_conv_boundary.3", reps * P4, 256, N2, H4, W4, True, mk)
+            b1 = self._bn_act(ctx, "decoder.last_conv_boundary.1", yb1, N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
+            yb2 = self._empty(x, reps * P4, 256)
+            st = self._stats(ctx, 256, True)
+            K.conv(b1, self._w(ctx, "decoder.last_conv_boundary.4.weight", "ohwi"), 3, 1, yb2, stats=st)
+            m, ms = self._mask(x, "decoder.last_conv_boundary.7", reps * P4, 256, N2, H4, W4, True, mk)
+            b2 = self._bn_act(ctx, "decoder.last_conv_boundary.5", yb2, N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
+            K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1, xf[:, 304:305],
+                   bias=params["decoder.last_conv_boundary.8.bias"])
+            st = self._stats(ctx, 305, True)
+            K.colstats(xf[:, :305], st)
+            m, ms = self._mask(x, "decoder.last_conv.2", reps * P4, 305, N2, H4, W4, True, mk)
+            sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
+            x1b = self._buf(x, reps * P4, 2)
+            K.conv(sa, self._w(ctx, "decoder.last_conv.3.weight", "ohwi"), 1, 1, x1b, bias=params["decoder.last_conv.3.bias"])
+            K.head_upsample_fwd(x1b, N2, H4, W4, out[ps * N2:(ps + 1) * N2])
+            ctx.arena = None
+            if ctx.nbt:      # the three stochastic BNs of this pass
+                torch._foreach_add_(ctx.nbt, 1)
+                ctx.nbt = []
+        # running statistics of the reused (deterministic) BNs: `passes` more updates on the repeated batch
+        stoch = set(self._STOCHASTIC_BN)
+        for prefix, rec in ctx.bnlog:
+            if prefix in stoch:
+                continue
+            K.bn_running_replay(rec.mean, rec.invstd, rec.count * reps, passes, BN_MOMENTUM, BN_EPS,
+                                params[prefix + ".running_mean"], params[prefix + ".running_var"])
+        nbt = [params[p + ".num_batches_tracked"] for p, _ in ctx.bnlog
+               if p not in stoch and (p + ".num_batches_tracked") in params]
+        if nbt:
+            torch._foreach_add_(nbt, passes)
+        # drop the per-pass records of the stochastic BNs again (bnlog describes the grad-mode forward)
+        ctx.bnlog = ctx.bnlog[:len(ctx.bnlog) - 3 * passes]
+        return out
 
     # ------------------------------------------------------------------ backward pieces
     def _bn_backward(self, ctx, G, y: Act, dU, out=None, addend=None, keys=None):

@@ -58,6 +58,7 @@ SYMBOLS = {
     "uda_stem_fwd": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P]),
     "uda_stem_wgrad": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "uda_bn_running_replay": (_I, [_P, _P, _I, _D, _I, _F, _F, _P, _P, _P]),
     "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "uda_bn_apply": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
     "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P]),
@@ -271,6 +272,13 @@ class HipKernels:
         self._ck(self.lib.uda_bn_finalize(stats.data_ptr(), Cc, float(count), gamma.data_ptr(), beta.data_ptr(),
                                           rmean.data_ptr(), rvar.data_ptr(), momentum, eps, scale.data_ptr(),
                                           shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), self._stream()))
+
+    def bn_running_replay(self, mean, invstd, count, k, momentum, eps, rmean, rvar):
+        Cc = mean.numel()
+        for t in (mean, invstd, rmean, rvar):
+            assert t.is_contiguous() and t.numel() == Cc
+        self._ck(self.lib.uda_bn_running_replay(mean.data_ptr(), invstd.data_ptr(), Cc, float(count), int(k), momentum, eps,
+                                                rmean.data_ptr(), rvar.data_ptr(), self._stream()))
 
     def bn_eval_coeffs(self, gamma, beta, rmean, rvar, eps, scale, shift):
         Cc = gamma.numel()

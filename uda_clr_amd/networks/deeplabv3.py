@@ -28,7 +28,9 @@ class _GeneratorFn(torch.autograd.Function):
         params = module._flat_state()
         masks, module._next_masks = module._next_masks, None
         outs, ectx = engine.forward(params, x, module._bn_training(), need_grad, masks)
-        ctx.engine, ctx.ectx, ctx.keys = engine, ectx, keys
+        ctx.engine, ctx.ectx, ctx.keys, ctx.module = engine, ectx, keys, module
+        if ectx is not None and module.training:
+            module._remember(x, ectx)
         return outs
 
     @staticmethod
@@ -36,6 +38,7 @@ class _GeneratorFn(torch.autograd.Function):
         if ctx.ectx is None:
             raise RuntimeError("generator forward ran without gradient bookkeeping")
         G = ctx.engine.backward(ctx.ectx, grads)
+        ctx.module._forget(ctx.ectx)          # its activations are consumed; parameters are about to change
         ctx.ectx = None
         return (None, None, None, None) + tuple(G.get(k) for k in ctx.keys)
 
@@ -54,6 +57,7 @@ class DeepLab(Holder):
         self.aspp = build_aspp(backbone, output_stride, BatchNorm)
         self.decoder = build_decoder(num_classes, backbone, method, BatchNorm)
         self._engine = None
+        self._recent = []                 # (input data_ptr, shape, engine ctx) of the last training forwards
         self._engine_override = None      # tests only: an engine bound to their torch kernel spec
         self._next_masks = None           # tests only: injected dropout keep-masks for one forward
         if freeze_bn:
@@ -83,6 +87,33 @@ class DeepLab(Holder):
     def set_dropout_masks(self, masks):
         """Parity tests: keep-masks ({site: uint8 NCHW}) used by the next training forward."""
         self._next_masks = masks
+
+    def _remember(self, x, ectx):
+        self._recent = [(x.data_ptr(), tuple(x.shape), ectx)] + self._recent[:1]
+
+    def _forget(self, ectx):
+        self._recent = [r for r in self._recent if r[2] is not ectx]
+
+    def mc_dropout_logits(self, x, passes=4, reps=2, masks=None):
+        """Segmentation logits of ``passes`` no-grad training-mode forwards on ``x.repeat(reps,1,1,1)``
+        (Trainer_prototype_full.py:358-368: T = passes*reps stochastic predictions per image), as one
+        [passes*reps*N, 2, H, W] tensor.  When ``x`` is the input of a recent grad-mode training forward
+        of this module (and no parameter changed since), the deterministic pre-dropout activations of
+        that forward are reused and only the dropout-dependent tail is recomputed
+        (``GeneratorEngine.mc_forward``); otherwise the passes run as plain forwards."""
+        assert self.training, "stochastic passes need training mode (dropout + batch statistics)"
+        for ptr, shape, ectx in self._recent:
+            if ptr == x.data_ptr() and shape == tuple(x.shape):
+                with torch.no_grad():
+                    return self._engine_for(x).mc_forward(ectx, reps, passes, masks=masks)
+        outs = []
+        with torch.no_grad():
+            xr = x.repeat(reps, 1, 1, 1)
+            for ps in range(passes):
+                if masks is not None:
+                    self.set_dropout_masks(masks[ps])
+                outs.append(self(xr)[0])
+        return torch.cat(outs, 0)
 
     def _flat_state(self):
         sd = {}

@@ -199,10 +199,15 @@ class Trainer(TrainerBase):
             T = 8
             volume_batch_r = imageT.repeat(2, 1, 1, 1)
             stride = volume_batch_r.shape[0] // 2
-            preds_trg = torch.empty([stride * T, 2, imageT.shape[2], imageT.shape[3]], device=imageT.device)
-            with torch.no_grad():                                                            # :364-368 (features_trg is dead, Q5)
-                for i in range(T // 2):
-                    preds_trg[2 * stride * i:2 * stride * (i + 1)] = gen(volume_batch_r)[0]
+            if hasattr(gen, "mc_dropout_logits"):
+                # fused form of :358-368: the deterministic pre-dropout part of the T forward above is
+                # reused, only the dropout-dependent decoder tail runs T/2 times on the doubled batch
+                preds_trg = gen.mc_dropout_logits(imageT, passes=T // 2, reps=2)
+            else:
+                preds_trg = torch.empty([stride * T, 2, imageT.shape[2], imageT.shape[3]], device=imageT.device)
+                with torch.no_grad():                                                        # :364-368 (features_trg is dead, Q5)
+                    for i in range(T // 2):
+                        preds_trg[2 * stride * i:2 * stride * (i + 1)] = gen(volume_batch_r)[0]
             if self.retrify_pesudo:
                 res = ops.gen_prototype_retrify(oT_before, xt_feature, preds_trg, None, T, stride)
                 cur_tgt = res[:4]

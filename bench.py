@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", choices=("prototype_full", "source_only"), default="prototype_full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dis-channels-last", action="store_true", help="run the stock-torch discriminators in channels_last")
     ap.add_argument("--miopen-benchmark", action="store_true", help="let MIOpen search conv algorithms for the stock-torch discriminators")
     args = ap.parse_args()
 
@@ -169,6 +170,8 @@ def main():
         per_step = args.batch
     else:
         d1, d2 = BoundaryDiscriminator().to(dev).train(), UncertaintyDiscriminator().to(dev).train()
+        if args.dis_channels_last:
+            d1, d2 = d1.to(memory_format=torch.channels_last), d2.to(memory_format=torch.channels_last)
         od = torch.optim.SGD(d1.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=5e-4)
         od2 = torch.optim.SGD(d2.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=5e-4)
         tr = Trainer_prototype_full.Trainer(

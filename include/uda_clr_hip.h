@@ -192,6 +192,13 @@ int uda_proto_bwd(const float* feat, int64_t ldf, int64_t P, int C, const float*
                   const float* dC, float* coef_ws /* float[4][C+1] */, float* d_feat, int64_t ldd,
                   int accumulate, float* d_w, void* stream);
 
+/* out[p][k] = sum_c feat[p,c]*coef[k][c] + coef[k][C], k < 4 (coef: float[4][C+1]) and its adjoint
+ * d_feat[p,c] (+)= sum_k wts[p][k]*coef[k][c].  Used by the prototype-guided discriminative loss
+ * (no shipped source - parity unpinned). */
+int uda_feat_dot4(const float* feat, int64_t ldf, int64_t P, int C, const float* coef, float* out, void* stream);
+int uda_feat_rank4(const float* wts, const float* coef, int64_t P, int C, float* d_feat, int64_t ldd,
+                   int accumulate, void* stream);
+
 /* ---- torch.optim.Adam update (no weight decay / amsgrad) over one flat fp32 buffer
  * (train_use_fix_initial.py:210-214) */
 int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -518,7 +518,26 @@ def case_adam(n, seed=13):
     return run
 
 
+def case_feat4(P, C, seed=14):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        feat = padded(P, C, g)
+        coef = torch.randn(4, C + 1, generator=g)
+        o_r = SPEC.feat_dot4(feat, coef)
+        o_h = K.feat_dot4(to_dev(feat, dev), coef.to(dev))
+        w = torch.randn(P, 4, generator=g)
+        base = padded(P, C, g)
+        d_r = base.clone()
+        SPEC.feat_rank4(w, coef, d_r, True)
+        d_h = to_dev(base, dev)
+        K.feat_rank4(w.to(dev), coef.to(dev), d_h, True)
+        return max(rel(o_h, o_r), rel(d_h, d_r)), 2e-5
+    return run
+
+
 CASES += [
+    ("feat dot4/rank4 C=305", case_feat4(3000, 305)),
     # wide warp-specialised tiles (BN = 256 needs >= 512 workgroups: P >= 65536)
     ("conv3x3 16->256 P=65536 (BN=256 tiles) relu mask", case_conv(4, 128, 128, 16, 256, 3, 1, mask=True)),
     ("conv1x1 64->200 P=65536 (BN=256 tiles) bias addend", case_conv(4, 128, 128, 64, 200, 1, 1, bias=True, addend=True)),
@@ -532,3 +551,25 @@ CASES += [
     ("proto hard C=64 h=8", case_proto(3, 8, 64, 0)),
     ("adam 100003", case_adam(100003)),
 ]
+
+
+def case_discriminative(B, h, C, seed=15):
+    """ops.discriminative_loss (HIP) against oracle/losses_ref.py (parity unpinned: our reading of Appendix B)."""
+    def run(dev):
+        from oracle import losses_ref
+        from uda_clr_amd import ops
+        g = gen(seed)
+        feat = torch.randn(B, C, h, h, generator=g)
+        cents = tuple(torch.randn(1, C, 1, 1, generator=g) for _ in range(4))
+        lab = (torch.rand(B, 2, h, h, generator=g) > 0.5).float()
+        f_r = feat.clone().requires_grad_(True)
+        l_r = losses_ref.discriminative_loss(f_r, cents, lab)
+        l_r.backward()
+        f_h = feat.to(dev).requires_grad_(True)
+        l_h = ops.discriminative_loss(f_h, tuple(c.to(dev) for c in cents), lab.to(dev))
+        l_h.backward()
+        return max(rel(l_h, l_r), rel(f_h.grad, f_r.grad)), 5e-5
+    return run
+
+
+CASES += [("discriminative loss (unpinned) C=305", case_discriminative(2, 16, 305))]

@@ -372,6 +372,17 @@ class SpecKernels:
             return (feat.double() @ coef.t() + extra).float()
         return None
 
+    def feat_dot4(self, feat, coef):
+        Cc = feat.shape[1]
+        return (feat.double() @ coef[:, :Cc].double().t() + coef[:, Cc].double()).float()
+
+    def feat_rank4(self, wts, coef, d_feat, accumulate=False):
+        g = (wts.double() @ coef[:, :d_feat.shape[1]].double()).float()
+        if accumulate:
+            d_feat.add_(g)
+        else:
+            d_feat.copy_(g)
+
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
         exp_avg.mul_(beta1).add_(grads, alpha=1 - beta1)
         exp_avg_sq.mul_(beta2).addcmul_(grads, grads, value=1 - beta2)

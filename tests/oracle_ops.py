@@ -3,7 +3,7 @@ tests drive the product Trainer classes' host logic (loop order, schedules, logg
 data-parallel plumbing) without a GPU.  Never imported by the product."""
 import torch.nn.functional as F
 
-from oracle import metrics_ref, proto_ref, step_ref
+from oracle import losses_ref, metrics_ref, proto_ref, step_ref
 
 
 class OracleOps:
@@ -11,6 +11,12 @@ class OracleOps:
     gen_prototype = staticmethod(proto_ref.gen_prototype)
     dice_coeff_2label = staticmethod(metrics_ref.dice_coeff_2label)
     pixel_acc = staticmethod(metrics_ref.pixel_acc)
+    discriminative_loss = staticmethod(losses_ref.discriminative_loss)
+    consistency_loss = staticmethod(losses_ref.consistency_loss)
+
+    @staticmethod
+    def photometric_augment(images, generator=None):
+        return images * 0.9
 
     @staticmethod
     def gen_prototype_from_labels(target_map, feature):

@@ -1,0 +1,56 @@
+"""not-gpu: the data harness behind the reference's import names (dataset layout, transform chain of
+train_use_fix_initial.py:150-166, sample format of custom_transforms.py:496-507)."""
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from uda_clr_amd.dataloaders import custom_transforms as tr
+from uda_clr_amd.dataloaders import fundus_dataloader as DL
+from uda_clr_amd.dataloaders.synthetic import write_dataset
+from uda_clr_amd.dropin import install
+
+
+class Compose:
+    def __init__(self, ts): self.ts = ts
+    def __call__(self, s):
+        for t in self.ts:
+            s = t(s)
+        return s
+
+
+def test_dataset_and_transform_chain(tmp_path):
+    random.seed(0); np.random.seed(0)
+    write_dataset(str(tmp_path), "refuge", "train", 5, size=160, seed=1)
+    train_tf = Compose([tr.RandomScaleCrop(128), tr.RandomRotate(), tr.RandomFlip(), tr.elastic_transform(),
+                        tr.add_salt_pepper_noise(), tr.adjust_light(), tr.eraser(), tr.Normalize_tf(), tr.ToTensor()])
+    ds = DL.FundusSegmentation(base_dir=str(tmp_path), dataset="refuge", split="train", transform=train_tf)
+    assert len(ds) == 5
+    for _ in range(3):                                    # several random draws of every branch
+        for batch in DataLoader(ds, batch_size=2, shuffle=True, num_workers=0):
+            img, mp, bd = batch["image"], batch["map"], batch["boundary"]
+            assert img.shape[1:] == (3, 128, 128) and mp.shape[1:] == (2, 128, 128) and bd.shape[1:] == (1, 128, 128)
+            assert img.dtype == mp.dtype == bd.dtype == torch.float32
+            assert -1.0 <= float(img.min()) and float(img.max()) <= 1.0
+            assert set(torch.unique(mp).tolist()) <= {0.0, 1.0}
+            assert bool((mp[:, 0] <= mp[:, 1]).all()), "cup must be a subset of disc"
+            assert 0.0 <= float(bd.min()) and float(bd.max()) <= 1.0 and float(bd.max()) > 0.2
+    test_tf = Compose([tr.RandomCrop(128), tr.Normalize_tf(), tr.ToTensor()])
+    s = DL.FundusSegmentation(base_dir=str(tmp_path), dataset="refuge", split="train", transform=test_tf)[0]
+    assert s["map"].sum() > 0 and isinstance(s["img_name"], str)
+
+
+def test_dropin_publishes_reference_import_names():
+    import sys
+    install()
+    from networks.deeplabv3 import DeepLab                                   # noqa: F401
+    from networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator   # noqa: F401
+    from train_process import Trainer, Trainer_baseline, Trainer_prototype_full  # noqa: F401
+    from dataloaders import fundus_dataloader, custom_transforms               # noqa: F401
+    from utils.Utils import gen_prototype, gen_prototype_retrify              # noqa: F401
+    from utils.metrics import dice_coeff_2label                               # noqa: F401
+    import mypath                                                              # noqa: F401
+    assert sys.modules["networks.deeplabv3"].__name__ == "uda_clr_amd.networks.deeplabv3"
+    for k in [k for k in sys.modules if k.split(".")[0] in ("networks", "train_process", "dataloaders", "mypath") or k in ("utils", "utils.Utils", "utils.metrics")]:
+        del sys.modules[k]

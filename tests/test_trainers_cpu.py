@@ -99,3 +99,27 @@ def test_union_signature_and_warmup_phase(tmp_path):
     with pytest.raises(NotImplementedError):
         Trainer_prototype_full.Trainer(False, m, d1, d2, og, od, od2, loader, loader, loader, str(tmp_path), 1,
                                        use_global=False, use_pid=True)
+
+
+def test_appendix_b_losses_are_wired_and_off_by_default(tmp_path):
+    """src_reg / use_trg_cons (parity unpinned): default off reproduces the shipped rows
+    (tested above); switched on, the step still runs, both extra terms are finite and they change the update."""
+    def run(**kw):
+        m = _oracle_model()
+        torch.manual_seed(5)
+        d1, d2 = BoundaryDiscriminator(), UncertaintyDiscriminator()
+        og, od, od2 = step_ref.make_optimizers(m, d1, d2)
+        loader = synth_loader(1, 2, 512, 41)
+        tr = Trainer_prototype_full.Trainer(False, m, d1, d2, og, od, od2, loader, loader, loader, str(tmp_path), 1,
+                                            use_global=True, use_pid=True, retrify_pesudo=True, global_pro_weight=0.9,
+                                            pro_weight=0.1, stop_epoch=1, warmup_epoch=-1, **kw)
+        tr.ops = OracleOps()
+        m.train(); d1.train(); d2.train()
+        torch.manual_seed(6)
+        tr.train_step(loader[0], loader[0])
+        return tr, torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    t0, p0 = run()
+    t1, p1 = run(src_reg=True, use_trg_cons=True, src_reg_weight=1.0, aug_weight=1.0)
+    assert not hasattr(t0, "loss_src_reg")
+    assert torch.isfinite(t1.loss_src_reg) and torch.isfinite(t1.loss_aug) and float(t1.loss_src_reg) > 0
+    assert not torch.equal(p0, p1)

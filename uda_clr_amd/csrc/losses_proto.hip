@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void proto_bwd_kernel(const float* __restrict_
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int C1 = C + 1;
     for (int64_t p = wave; p < P; p += nwaves) {
-        const float4 w = uda_ld4(wts + p * 4);
+        const float4 w = d_feat ? uda_ld4(wts + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
         for (int c = lane; c < C; c += 64) {
             const float k0 = coef[c], k1 = coef[C1 + c], k2 = coef[2 * C1 + c], k3 = coef[3 * C1 + c];
@@ -387,6 +387,29 @@ extern "C" int uda_proto_bwd(const float* feat, int64_t ldf, int64_t P, int C, c
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(proto_bwd_kernel, dim3(grid), dim3(256), 0, st, feat, ldf, P, C, wts, coef_ws, d_feat, ldd, accumulate, d_w);
     UDA_LAUNCH_CHECK("proto_bwd");
+    return 0;
+}
+
+/* out[p][k] = sum_c feat[p,c] * coef[k][c] + coef[k][C]   (4 affine functionals of every pixel's feature vector;
+ * the prototype-guided discriminative loss needs D(f,c_obj) - D(f,c_bck), which is affine in f) */
+extern "C" int uda_feat_dot4(const float* feat, int64_t ldf, int64_t P, int C, const float* coef, float* out, void* stream) {
+    UDA_REQUIRE(feat && coef && out && uda_aligned16(out) && P > 0 && C > 0 && ldf >= C, "uda_feat_dot4: bad args");
+    int grid = uda_cdiv(P, 4);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(proto_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, ldf, P, C, (const float*)nullptr, coef,
+                       (float*)nullptr, (int64_t)0, 0, out);
+    UDA_LAUNCH_CHECK("feat_dot4");
+    return 0;
+}
+/* d_feat[p,c] (+)= sum_k wts[p][k] * coef[k][c]   (adjoint of uda_feat_dot4) */
+extern "C" int uda_feat_rank4(const float* wts, const float* coef, int64_t P, int C, float* d_feat, int64_t ldd, int accumulate,
+                              void* stream) {
+    UDA_REQUIRE(wts && uda_aligned16(wts) && coef && d_feat && P > 0 && C > 0 && ldd >= C, "uda_feat_rank4: bad args");
+    int grid = uda_cdiv(P, 4);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(proto_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, (int64_t)0, P, C, wts,
+                       coef, d_feat, ldd, accumulate, (float*)nullptr);
+    UDA_LAUNCH_CHECK("feat_rank4");
     return 0;
 }
 

@@ -81,6 +81,8 @@ SYMBOLS = {
     "uda_proto_reduce": (_I, [_P, _L, _L, _I, _P, _P, _P, _U, _P]),
     "uda_proto_finalize": (_I, [_P, _I, _P, _P]),
     "uda_proto_bwd": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "uda_feat_dot4": (_I, [_P, _L, _L, _I, _P, _P, _P]),
+    "uda_feat_rank4": (_I, [_P, _P, _L, _I, _P, _L, _I, _P]),
     "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
 }
 
@@ -466,6 +468,22 @@ class HipKernels:
         self._ck(self.lib.uda_proto_bwd(f, ldf, P, Cc, wts.data_ptr(), sums.data_ptr(), dC.data_ptr(), coef.data_ptr(),
                                         dptr, ldd, int(accumulate), _ptr(d_w), self._stream()))
         return d_w
+
+    def feat_dot4(self, feat, coef):
+        """[P,4]: feat @ coef[:, :C].T + coef[:, C]"""
+        f, ldf = _mat(feat, "feat")
+        P, Cc = feat.shape
+        assert coef.is_contiguous() and tuple(coef.shape) == (4, Cc + 1) and coef.dtype == torch.float32
+        out = torch.empty(P, 4, dtype=torch.float32, device=feat.device)
+        self._ck(self.lib.uda_feat_dot4(f, ldf, P, Cc, coef.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def feat_rank4(self, wts, coef, d_feat, accumulate=False):
+        """d_feat (+)= wts @ coef[:, :C]"""
+        d, ldd = _mat(d_feat, "d_feat")
+        P, Cc = d_feat.shape
+        assert wts.is_contiguous() and tuple(wts.shape) == (P, 4) and tuple(coef.shape) == (4, Cc + 1) and coef.is_contiguous()
+        self._ck(self.lib.uda_feat_rank4(wts.data_ptr(), coef.data_ptr(), P, Cc, d, ldd, int(accumulate), self._stream()))
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):

@@ -126,6 +126,95 @@ def gen_prototype_retrify(oT_before, xt_feature, preds, features, T, stride):
     return cents + (std_map, m0.reshape(B, 1, h, w), m1.reshape(B, 1, h, w))
 
 
+class _DiscriminativeFn(torch.autograd.Function):
+    """Prototype-guided discriminative loss on the source features (no shipped
+    source - parity unpinned).  D(f,c) = mean_c (f-c)^2, so D(f,c_obj) - D(f,c_bck) is AFFINE in f:
+        diff_k[p] = -(2/C) f[p,:].(c_obj - c_bck) + (|c_obj|^2 - |c_bck|^2)/C
+    one pass over the 305-channel feature (uda_feat_dot4) gives both classes' differences, and the
+    gradient is a per-pixel scalar times the constant vector (c_bck - c_obj) (uda_feat_rank4)."""
+
+    @staticmethod
+    def forward(ctx, feature, cents, labels, margin):
+        K = kernels()
+        rows = rows_view(feature)
+        P, C = rows.shape
+        B, _, H, W = feature.shape
+        c = cents.detach().float()                      # [4, C]: cup_obj, disc_obj, cup_bck, disc_bck
+        coef = torch.zeros(4, C + 1, dtype=torch.float32, device=rows.device)
+        for k in (0, 1):
+            coef[k, :C] = (-2.0 / C) * (c[k] - c[k + 2])
+            coef[k, C] = (c[k].pow(2).sum() - c[k + 2].pow(2).sum()) / C
+        diff = K.feat_dot4(rows, coef)[:, :2]                                  # [P, 2]
+        m = labels.detach().permute(0, 2, 3, 1).reshape(P, 2).float()
+        pos, neg = diff + margin, margin - diff
+        loss = ((m * torch.relu(pos)).sum(0) + ((1 - m) * torch.relu(neg)).sum(0)).sum() / P
+        ctx.save_for_backward(coef, m, diff)
+        ctx.geom, ctx.margin = (B, C, H, W), margin
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        coef, m, diff = ctx.saved_tensors
+        B, C, H, W = ctx.geom
+        P = m.shape[0]
+        s = (m * (diff + ctx.margin > 0).float() - (1 - m) * (ctx.margin - diff > 0).float()) * (g / P)
+        wts = torch.zeros(P, 4, dtype=torch.float32, device=m.device)
+        wts[:, :2] = s
+        d_rows = torch.empty(P, round4(C), dtype=torch.float32, device=m.device)[:, :C]
+        kernels().feat_rank4(wts, coef, d_rows, False)
+        return nchw_view(d_rows, B, H, W), None, None, None
+
+
+def discriminative_loss(feature, centroids, labels, margin=0.01):
+    """centroids: the 4-tuple (cup_obj, disc_obj, cup_bck, disc_bck) of [1,C,1,1] prototypes (detached)."""
+    cents = torch.cat([t.reshape(1, -1) for t in centroids], 0)
+    return _DiscriminativeFn.apply(feature, cents, labels, margin)
+
+
+def photometric_augment(images, generator=None):
+    """Device-side photometric augmentation of a [-1,1] image batch in the spirit of utils/Utils.py:33-43
+    (brightness/contrast + saturation jitter with p=0.8, grayscale with p=0.2, 5x5 Gaussian blur with
+    p=0.5; geometry and labels unchanged).  The reference does this per image on the CPU with
+    albumentations/cv2; the exact random streams are not reproducible, so this is 'same family, same
+    probabilities' (parity unpinned)."""
+    B = images.shape[0]
+    dev = images.device
+    r = lambda *s: torch.rand(*s, generator=generator, device="cpu").to(dev)
+    x = (images + 1.0) * 0.5
+    on = (r(B, 1, 1, 1) < 0.8).float()
+    alpha = 1.0 + on * (r(B, 1, 1, 1) * 0.4 - 0.2)               # contrast  in [0.8, 1.2]
+    beta = on * (r(B, 1, 1, 1) * 0.4 - 0.2)                        # brightness in [-0.2, 0.2]
+    x = (x * alpha + beta * x.mean((1, 2, 3), keepdim=True)).clamp(0, 1)
+    gray = x.mean(1, keepdim=True)
+    sat = 1.0 + on * (r(B, 1, 1, 1) * 0.6 - 0.3)
+    x = (gray + (x - gray) * sat).clamp(0, 1)
+    tg = (r(B, 1, 1, 1) < 0.2).float()
+    x = tg * gray.expand_as(x) + (1 - tg) * x
+    k = torch.tensor([1., 4., 6., 4., 1.], device=dev)
+    k = (k[:, None] * k[None, :] / 256.0).expand(3, 1, 5, 5)
+    blur = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (2, 2, 2, 2), mode="reflect"), k, groups=3)
+    bl = (r(B, 1, 1, 1) < 0.5).float()
+    x = bl * blur + (1 - bl) * x
+    return x * 2.0 - 1.0
+
+
+def consistency_threshold(epoch, rampup=200):
+    import math
+    phase = 1.0 - min(max(float(epoch), 0.0), rampup) / rampup
+    return (0.85 + 0.25 * math.exp(-5.0 * phase * phase)) * math.log(2.0)
+
+
+def consistency_loss(oT_aug, oT, mask_0, mask_1, epoch, aug_weight=1.0):
+    """aug_weight * sum(mask * BCE(sigmoid(oT_aug), [sigmoid(oT) > tau(epoch)])) / sum(mask), mask = nearest-
+    upsampled cat(mask_0, mask_1) (parity unpinned).  Elementwise torch ops on
+    two 512x512x2 maps per image - not worth a kernel of their own yet."""
+    F = torch.nn.functional
+    y = (torch.sigmoid(oT.detach()) > consistency_threshold(epoch)).to(oT.dtype)
+    mask = F.interpolate(torch.cat((mask_0, mask_1), 1), size=oT.shape[2:], mode="nearest")
+    bce = F.binary_cross_entropy(torch.sigmoid(oT_aug), y, reduction="none")
+    return aug_weight * (mask * bce).sum() / mask.sum().clamp_min(1e-12)
+
+
 def seg_counts(pred, target, thr=0.75):
     """int64 [C,3] on the host: (intersection, predicted, ground truth) for sigmoid(pred) > thr."""
     return kernels().seg_counts(pred.detach().contiguous().float(), target.detach().contiguous().float(), thr).cpu()

@@ -46,7 +46,8 @@ class Trainer(TrainerBase):
                  use_global=True, use_pid=False, retrify_pesudo=False, global_pro_weight=0.9, pro_weight=0.1,
                  stop_epoch=None, lr_gen=1e-3, lr_dis=1e-3, lr_decrease_rate=0.1, interval_validate=None,
                  batch_size=8, warmup_epoch=25, target_name='Drishti-GS',
-                 model_geninitial_pesudolabel=None, use_fix_initial=False, use_TN=False):
+                 model_geninitial_pesudolabel=None, use_fix_initial=False, use_TN=False,
+                 use_trg_cons=False, src_reg=False, aug_weight=1.0, src_reg_weight=1.0):
         self.First_src = True
         self.First = True
         self.target_name = target_name
@@ -61,6 +62,9 @@ class Trainer(TrainerBase):
         self.model_geninitial_pesudolabel = model_geninitial_pesudolabel     # accepted, unused (as shipped)
         self.use_fix_initial = use_fix_initial
         self.use_TN = use_TN
+        # the two losses of SURVEY.md Appendix B (no shipped source, parity unpinned); off = shipped behaviour
+        self.use_trg_cons, self.src_reg = use_trg_cons, src_reg
+        self.aug_weight, self.src_reg_weight = aug_weight, src_reg_weight
         self.model_dis2 = model_uncertainty_dis
         self.model_dis = model_dis
         self.optim_gen = optimizer_gen
@@ -218,6 +222,9 @@ class Trainer(TrainerBase):
             intra_loss = sum(mseloss(s, t) for s, t in zip(src, tgt))                        # :428-441
             inter_loss = mseloss(src[1], src[3]) + mseloss(src[0], src[2])                   # :443-444 (logged only)
             self.First_src = self.First = False
+            if self.src_reg:                                                                 # Appendix B (unpinned)
+                pred_oS = F.interpolate(target_map, size=xs_feature.shape[2:], mode='nearest')
+                self.loss_src_reg = ops.discriminative_loss(xs_feature, src, pred_oS)
         uncertainty_mapT = self._uncertainty(oT)                                             # :452-458
         D_out2 = dis(torch.sigmoid(boundaryT))
         D_out1 = dis2(uncertainty_mapT)
@@ -226,7 +233,16 @@ class Trainer(TrainerBase):
         loss_all = loss_seg + loss_adv_diff
         if intra_loss is not None:
             loss_all = loss_all + (self.pro_weight * self.world) * intra_loss                # :465 (x world: see module doc)
+            if self.src_reg:
+                loss_all = loss_all + self.src_reg_weight * self.loss_src_reg
         loss_all.backward()
+        if self.use_trg_cons and intra_loss is not None and self.retrify_pesudo:             # Appendix B (unpinned)
+            # augmented consistency: pseudo labels of the clean target prediction supervise the prediction on
+            # a photometrically augmented copy, on the pixels the MC-dropout std marked reliable
+            oT_aug = gen(ops.photometric_augment(imageT))[0]
+            loss_aug = ops.consistency_loss(oT_aug, oT, self.mask_0, self.mask_1, self.epoch, self.aug_weight)
+            loss_aug.backward()
+            self.loss_aug = loss_aug.detach()
         if self._reducers is not None:
             self._reducers[0].all_reduce_mean()
         self.optim_gen.step()

@@ -54,6 +54,9 @@ class HipOps:
         self.gen_prototype_from_labels = ops.gen_prototype_from_labels
         self.gen_prototype = ops.gen_prototype
         self.gen_prototype_retrify = ops.gen_prototype_retrify
+        self.discriminative_loss = ops.discriminative_loss
+        self.photometric_augment = ops.photometric_augment
+        self.consistency_loss = ops.consistency_loss
         self.dice_coeff_2label = metrics.dice_coeff_2label
         self.pixel_acc = metrics.pixel_acc
 

@@ -1,4 +1,4 @@
-"""Functional CPU restatement of the reference generator (DeepLabV3+ / MobileNetV2).
+"""Functional CPU restatement of the reference generator (DeepLabV3+ on MobileNetV2 or ResNet-101).
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  The network is evaluated directly
 on a flat ``state_dict`` (reference key names) with ``torch.nn.functional`` ops,
@@ -9,6 +9,8 @@ Reference anchors
   networks/backbone/mobilenet.py   :8-13 stem, :16-22 fixed_padding, :25-67
                                    InvertedResidual, :77-86 block table,
                                    :93-101 output-stride/dilation rule, :116-122 split
+  networks/backbone/resnet.py      :23-43 Bottleneck.forward, :47-70 strides/dilations/MG unit,
+                                   :113-124 ResNet.forward (low-level = layer1 output)
   networks/aspp.py:65-78           ASPP.forward
   networks/decoder.py:45-56        Decoder.forward
 
@@ -101,14 +103,52 @@ def _inverted_residual(c, x, pre, inp, oup, stride, dil, t):
     return h
 
 
-def deeplab_forward(sd, x, training=True, masks=None, record=None, output_stride=16):
-    """Returns (x1, x2, feature, x_bu_feature, x_feature, x1_before, x2_before).
+def resnet_blocks(output_stride=16, layers=(3, 4, 23)):
+    """[(prefix, inplanes, planes, stride, dilation, has_downsample)] of ResNet-101 as the reference
+    builds it (resnet.py:47-111): three plain layers, then the multi-grid unit [1,2,4] x dilation."""
+    strides, dils = ((1, 2, 2, 1), (1, 1, 1, 2)) if output_stride == 16 else ((1, 2, 1, 1), (1, 1, 2, 4))
+    out, inp = [], 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256), layers)):
+        for b in range(n):
+            s = strides[li] if b == 0 else 1
+            out.append(("backbone.layer%d.%d" % (li + 1, b), inp, planes, s, dils[li],
+                        b == 0 and (s != 1 or inp != planes * 4)))
+            inp = planes * 4
+    for b, mg in enumerate((1, 2, 4)):
+        s = strides[3] if b == 0 else 1
+        out.append(("backbone.layer4.%d" % b, inp, 512, s, mg * dils[3], b == 0 and (s != 1 or inp != 2048)))
+        inp = 2048
+    return out
 
-    ``sd`` maps reference state-dict keys to tensors; BN running stats in it are
-    updated in place when ``training`` (deeplabv3.py:32-41).
-    """
-    c = _Ctx(sd, training, masks, record)
-    # --- backbone (mobilenet.py:8-13, 116-122)
+
+def _bottleneck(c, x, pre, stride, dil, has_ds):
+    # resnet.py:23-43
+    sd = c.sd
+    h = F.relu(c.bn(F.conv2d(x, sd[pre + ".conv1.weight"]), pre + ".bn1"))
+    h = F.relu(c.bn(F.conv2d(h, sd[pre + ".conv2.weight"], None, stride, dil, dil), pre + ".bn2"))
+    h = c.bn(F.conv2d(h, sd[pre + ".conv3.weight"]), pre + ".bn3")
+    res = x
+    if has_ds:
+        res = c.bn(F.conv2d(x, sd[pre + ".downsample.0.weight"], None, stride), pre + ".downsample.1")
+    return F.relu(h + res)
+
+
+def _resnet_backbone(c, x, output_stride):
+    # resnet.py:113-124
+    sd = c.sd
+    h = F.relu(c.bn(F.conv2d(x, sd["backbone.conv1.weight"], None, 2, 3), "backbone.bn1"))
+    h = F.max_pool2d(h, 3, 2, 1)
+    low = None
+    for pre, inp, planes, stride, dil, has_ds in resnet_blocks(output_stride):
+        if pre == "backbone.layer2.0":
+            low = h
+        h = _bottleneck(c, h, pre, stride, dil, has_ds)
+    return h, low
+
+
+def _mobilenet_backbone(c, x, output_stride):
+    # mobilenet.py:8-13, 116-122
+    sd = c.sd
     h = F.conv2d(x, sd["backbone.features.0.0.weight"], None, 2, 1)
     h = F.hardtanh(c.bn(h, "backbone.features.0.1"), 0.0, 6.0)
     low = None
@@ -116,6 +156,21 @@ def deeplab_forward(sd, x, training=True, masks=None, record=None, output_stride
         h = _inverted_residual(c, h, "backbone.features.%d" % i, inp, oup, stride, dil, t)
         if i == 3:
             low = h
+    return h, low
+
+
+def deeplab_forward(sd, x, training=True, masks=None, record=None, output_stride=16):
+    """Returns (x1, x2, feature, x_bu_feature, x_feature, x1_before, x2_before).
+
+    ``sd`` maps reference state-dict keys to tensors; BN running stats in it are
+    updated in place when ``training`` (deeplabv3.py:32-41).  The backbone is told
+    from the keys (``backbone.conv1.weight`` exists only in the ResNet).
+    """
+    c = _Ctx(sd, training, masks, record)
+    if "backbone.conv1.weight" in sd:
+        h, low = _resnet_backbone(c, x, output_stride)
+    else:
+        h, low = _mobilenet_backbone(c, x, output_stride)
     # --- ASPP (aspp.py:65-78)
     dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
     br = []

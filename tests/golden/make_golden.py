@@ -11,6 +11,7 @@ SURVEY.md section 8c (no edits to the reference, nothing copied from it), feeds 
 inputs and stores inputs' seeds + expected outputs as small data files:
 
   manifest.json          state-dict keys/shapes of DeepLab(mobilenet) + seeded-init checksums
+  manifest_resnet.json   the same for DeepLab(resnet) (ResNet-101, pretrained fetch patched out)
   forward_*.npz          7-tuple outputs (checksums + strided samples), BN running stats,
                          seg loss and per-parameter gradient norms (eval / train, 64^2 / 512^2)
   proto.npz              gen_prototype / gen_prototype_retrify inputs (by seed) and outputs
@@ -80,10 +81,10 @@ def install_reference():
     resnet.ResNet._load_pretrained_model = lambda self: None
 
 
-def ref_model(seed=1337):
+def ref_model(seed=1337, backbone="mobilenet"):
     from networks.deeplabv3 import DeepLab
     torch.manual_seed(seed)
-    return DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True,
+    return DeepLab(num_classes=2, backbone=backbone, output_stride=16, sync_bn=True,
                    freeze_bn=False, method="prototype_full")
 
 
@@ -131,8 +132,8 @@ def check(name, a, b, tol=1e-5):
 
 
 # ----------------------------------------------------------------------------- fixtures
-def make_manifest():
-    m = ref_model()
+def make_manifest(backbone="mobilenet", fname="manifest.json"):
+    m = ref_model(backbone=backbone)
     sd = m.state_dict()
     entries = [{"key": k, "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
                 "sum": float(v.double().sum())} for k, v in sd.items()]
@@ -142,7 +143,7 @@ def make_manifest():
            "param_sum": float(sum(p.double().sum() for p in params)),
            "param_abs_sum": float(sum(p.double().abs().sum() for p in params)),
            "seed": 1337, "entries": entries}
-    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+    with open(os.path.join(HERE, fname), "w") as f:
         json.dump(man, f, indent=0)
     print("manifest: %d keys, %d param tensors, %d params, sum=%.6f" %
           (man["n_state_keys"], man["n_param_tensors"], man["n_params"], man["param_sum"]))
@@ -395,7 +396,14 @@ def make_trainer_proto(tmp):
 if __name__ == "__main__":
     import tempfile
     install_reference()
-    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp"]
+    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn"]
+    if "rn" in which:        # ResNet-101 variant (BASELINE.json configs[4]); pretrained fetch patched out (8c)
+        mr = make_manifest("resnet", "manifest_resnet.json")
+        make_forward(mr, 2, 64, "resnet_64")
+        make_forward(mr, 2, 128, "resnet_128")
+        del mr
+        if which == ["rn"]:
+            raise SystemExit(0)
     m = make_manifest() if "manifest" in which else ref_model()
     if "fwd64" in which:
         make_forward(m, 2, 64, "64")

@@ -53,7 +53,8 @@ def main():
             fwd, grads, stats = model_cases.train_parity(dev)
             emit("train fwd parity: %s" % {k: "%.2e" % v for k, v in fwd.items()})
             emit("running stats err: %.2e" % stats)
-            bad = {k: v for k, v in grads.items() if not model_cases.grad_ok(v[0], v[1])}
+            bad, gmean = model_cases.grads_ok(grads)
+            print('gradient geometric-mean ratio hip/fp32 distance: %.2f' % gmean)
             worst = max(grads.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1e-4))
             emit("grad parity: %d params, %d outside 3x the fp32 noise floor; worst %s err %.2e floor %.2e" %
                  (len(grads), len(bad), worst[0], worst[1][0], worst[1][1]))

@@ -36,11 +36,23 @@ def l2rel(a, b, trim=0.01):
     return d.norm().item() / max(b.norm().item(), 1e-5)
 
 
-def grad_ok(err_hip, err_fp32_oracle):
-    """Gradient criterion.  The fp64 oracle is the ground truth; the fp32 oracle (= the reference's
-    own arithmetic) is itself 1e-3 .. 1e0 away from it on this network (BN-bias gradients are sums
-    with near-total cancellation), so the HIP path must stay within a small multiple of THAT distance."""
-    return err_hip < 5.0 * err_fp32_oracle + 2e-3
+def grad_ok(err_hip, err_fp32_oracle, factor=10.0):
+    """Per-tensor gradient criterion.  The fp64 oracle is the ground truth; the fp32 oracle (= the
+    reference's own arithmetic) is itself 1e-3 .. 1e0 away from it on this network (BN-bias gradients are
+    sums with near-total cancellation), so the HIP path must stay within a multiple of THAT distance.
+    Two fp32 evaluation orders of an ill-conditioned sum differ by a heavy-tailed random factor, so the
+    per-tensor bound is 10x and ``grads_ok`` adds a bound of 4x on the geometric mean over all tensors
+    (a wrong kernel moves a tensor by O(1), i.e. 100-1000x its fp32 distance)."""
+    return err_hip < factor * err_fp32_oracle + 2e-3
+
+
+def grads_ok(grads):
+    """grads: {key: (err_hip, err_fp32_oracle)} -> (offending keys, geometric-mean ratio)."""
+    import math
+    bad = {k: v for k, v in grads.items() if not grad_ok(v[0], v[1])}
+    ratios = [math.log(max(v[0], 1e-7) / max(v[1], 1e-7)) for v in grads.values()]
+    gmean = math.exp(sum(ratios) / max(len(ratios), 1))
+    return bad, gmean
 
 
 def seeded_model(seed=1337, perturb=False):

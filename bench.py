@@ -80,13 +80,13 @@ class ConvTimer:
                 "algorithmic_gflop_per_launch": round(sum(self.flops) / len(ms) / 1e9, 2)}
 
 
-def cpu_baseline(workload, B, S):
+def cpu_baseline(workload, B, S, backbone="mobilenet"):
     """The oracle restatement of the same step on the host cores (bounded sample)."""
     from oracle import deeplab_ref, step_ref
     from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
     from uda_clr_amd.networks.deeplabv3 import DeepLab
     torch.manual_seed(1337)
-    sd = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16).state_dict()
+    sd = DeepLab(num_classes=2, backbone=backbone, output_stride=16).state_dict()
     om = deeplab_ref.OracleDeepLab(sd).train()
     img, tmap, tbd = synth_batch(B, S, 1337, "cpu")
     imgT = synth_batch(B, S, 4242, "cpu")[0]
@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="source (and target) images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", choices=("prototype_full", "source_only"), default="prototype_full")
+    ap.add_argument("--backbone", choices=("mobilenet", "resnet"), default="mobilenet",
+                    help="resnet = the ResNet-101 variant of BASELINE.json configs[4] (quoted at --batch 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dis-channels-last", action="store_true", help="run the stock-torch discriminators in channels_last")
     ap.add_argument("--miopen-benchmark", action="store_true", help="let MIOpen search conv algorithms for the stock-torch discriminators")
@@ -145,7 +147,7 @@ def main():
     from uda_clr_amd.train_process import Trainer_baseline, Trainer_prototype_full
     load_library()
     torch.manual_seed(1337)
-    model = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True, freeze_bn=False,
+    model = DeepLab(num_classes=2, backbone=args.backbone, output_stride=16, sync_bn=True, freeze_bn=False,
                     method=args.workload).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.99))
     img, tmap, tbd = synth_batch(args.batch, args.size, 1337 + rank, dev)
@@ -216,6 +218,9 @@ def main():
                                   "adversarial G/D steps), DeepLabV3+/MobileNetV2 %dx%d bs=%d src + %d tgt per GPU "
                                   "(BASELINE.json configs[2]; images/sec counts src+tgt)"}[args.workload]
         fmt = (args.size, args.size, args.batch) + ((args.batch,) if args.workload == "prototype_full" else ())
+        if args.backbone == "resnet":
+            desc = desc.replace("DeepLabV3+/MobileNetV2", "DeepLabV3+/ResNet-101").replace("configs[1]", "configs[4] shape, 1 GPU").replace(
+                "configs[2]", "configs[4] shape, 1 GPU")
         line = {
             "metric": "training images/sec (512x512, src+tgt) at 1/2/4/8 MI355X; val Dice vs ref",
             "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -226,7 +231,7 @@ def main():
             "roofline": timer.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size)
+            line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size, args.backbone)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

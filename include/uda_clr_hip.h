@@ -109,6 +109,28 @@ int uda_stem_fwd(const float* x, int N, int H, int W, const float* w, float* y, 
 int uda_stem_wgrad(const float* x, int N, int H, int W, const float* dy, int64_t lddy, float* dw,
                    float* workspace, uint64_t workspace_bytes, void* stream);
 
+/* ---- ResNet-101 variant (BASELINE.json configs[4]; networks/backbone/resnet.py)
+ * conv1 7x7 stride 2 pad 3, 3 -> 64, NCHW image in, NHWC out (resnet.py:59,114); W % 8 == 0 */
+uint64_t uda_stem7_workspace_bytes(int64_t Pout);
+int uda_stem7_fwd(const float* x, int N, int H, int W, const float* w, float* y, int64_t ldy,
+                  double* stats /* [SLOTS][2][64] or NULL */, void* stream);
+int uda_stem7_wgrad(const float* x, int N, int H, int W, const float* dy, int64_t lddy, float* dw,
+                    float* workspace, uint64_t workspace_bytes, void* stream);
+/* MaxPool2d(3, 2, 1) of the pending transform of src (resnet.py:63,117).  idx[p,c] = winning tap
+ * kh*3+kw (first maximum in scan order, as ATen); the backward gathers dz through idx. */
+int uda_maxpool_fwd(const uda_src_t* src, float* out, int64_t ldo, uint8_t* idx, int64_t ldi, void* stream);
+int uda_maxpool_bwd(const float* dz, int64_t lddz, const uint8_t* idx, int64_t ldi, int N, int H, int W,
+                    int C, float* du, int64_t ldu, void* stream);
+/* every stride-th pixel of an [N,H,W,C] matrix (scatter = 0) or the transpose, zero insertion
+ * (scatter = 1, dst is the H x W side): the stride-2 convs of resnet.py:13,76-79 around the stride-1 kernels */
+int uda_rows_stride(const float* src, int64_t ld_src, int N, int H, int W, int C, int stride, int scatter,
+                    float* dst, int64_t ld_dst, void* stream);
+/* Bottleneck tail (resnet.py:37-41): out = relu(transform(a) + transform(b)) */
+int uda_bn_add_relu(const uda_src_t* a, const uda_src_t* b, float* out, int64_t ldo, void* stream);
+/* its backward gate: out = dz where z > 0 else 0 */
+int uda_relu_gate(const float* dz, int64_t lddz, const float* z, int64_t ldz, int64_t P, int C, float* out,
+                  int64_t ldo, void* stream);
+
 /* ---- batch-norm pieces (F.batch_norm, training and eval) */
 /* stats: double[UDA_STAT_SLOTS][2][C] */
 int uda_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,

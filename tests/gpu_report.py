@@ -50,7 +50,7 @@ def main():
             for S in (64, 96):
                 e = model_cases.eval_parity(dev, 2, S)
                 emit("eval parity %d: %s" % (S, {k: "%.2e" % v for k, v in e.items()}))
-            fwd, grads, stats = model_cases.train_parity(dev)
+            fwd, grads, stats, _ = model_cases.train_parity(dev)
             emit("train fwd parity: %s" % {k: "%.2e" % v for k, v in fwd.items()})
             emit("running stats err: %.2e" % stats)
             bad, gmean = model_cases.grads_ok(grads)

@@ -573,3 +573,98 @@ def case_discriminative(B, h, C, seed=15):
 
 
 CASES += [("discriminative loss (unpinned) C=305", case_discriminative(2, 16, 305))]
+
+
+# ------------------------------------------------------------------ ResNet-101 pieces
+def case_stem7(N, H, W, seed=16):
+    def run(dev):
+        g = gen(seed)
+        x = torch.randn(N, 3, H, W, generator=g)
+        w = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        y_r, st_r = padded(Po, 64, g), torch.zeros(16, 2, 64, dtype=torch.float64)
+        SPEC.stem7_fwd(x, w, y_r, st_r)
+        K = hip()
+        y_h, st_h = to_dev(padded(Po, 64, g), dev), torch.zeros(16, 2, 64, dtype=torch.float64, device=dev)
+        K.stem7_fwd(x.to(dev), w.to(dev), y_h, st_h)
+        dy = padded(Po, 64, g)
+        dw_r, dw_h = torch.empty(64, 3, 7, 7), torch.empty(64, 3, 7, 7, device=dev)
+        SPEC.stem7_wgrad(x, dy, dw_r)
+        K.stem7_wgrad(x.to(dev), to_dev(dy, dev), dw_h)
+        DETAIL.update(y=rel(y_h, y_r), stats=rel(st_h.sum(0), st_r.sum(0)), dw=rel(dw_h, dw_r))
+        return max(DETAIL.values()), 3e-5
+    return run
+
+
+def case_maxpool(N, H, W, C, seed=17):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        src = make_src(N, H, W, C, g, lazy=True, act=ACT_RELU)
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        z_r, i_r = padded(Po, C, g), torch.zeros(Po, round4(C), dtype=torch.uint8)[:, :C]
+        SPEC.maxpool_fwd(src, z_r, i_r)
+        z_h, i_h = to_dev(padded(Po, C, g), dev), torch.zeros(Po, round4(C), dtype=torch.uint8, device=dev)[:, :C]
+        K.maxpool_fwd(act_to(src, dev), z_h, i_h)
+        dz = padded(Po, C, g)
+        du_r, du_h = padded(N * H * W, C, g), to_dev(padded(N * H * W, C, g), dev)
+        SPEC.maxpool_bwd(dz, i_r, N, H, W, du_r)
+        K.maxpool_bwd(to_dev(dz, dev), i_h, N, H, W, du_h)
+        DETAIL.update(z=rel(z_h, z_r), idx=float((i_h.cpu() != i_r).sum()), du=rel(du_h, du_r))
+        return max(DETAIL.values()), 1e-6
+    return run
+
+
+def case_rows_stride(N, H, W, C, s, seed=18):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        Po = N * ((H - 1) // s + 1) * ((W - 1) // s + 1)
+        big, small = padded(N * H * W, C, g), padded(Po, C, g)
+        o_r, o_h = padded(Po, C, g), to_dev(padded(Po, C, g), dev)
+        SPEC.rows_stride(big, N, H, W, s, o_r)
+        K.rows_stride(to_dev(big, dev), N, H, W, s, o_h)
+        f_r, f_h = padded(N * H * W, C, g), to_dev(padded(N * H * W, C, g), dev)
+        SPEC.rows_stride(small, N, H, W, s, f_r, scatter=True)
+        K.rows_stride(to_dev(small, dev), N, H, W, s, f_h, scatter=True)
+        return max(rel(o_h, o_r), rel(f_h, f_r)), 0.0
+    return run
+
+
+def case_bottleneck_tail(N, H, W, C, seed=19):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        a = make_src(N, H, W, C, g, lazy=True, act=ACT_NONE)
+        errs = []
+        for lazy_b in (False, True):
+            b = make_src(N, H, W, C, g, lazy=lazy_b, act=ACT_NONE)
+            z_r, z_h = padded(a.P, C, g), to_dev(padded(a.P, C, g), dev)
+            SPEC.bn_add_relu(a, b, z_r)
+            K.bn_add_relu(act_to(a, dev), act_to(b, dev), z_h)
+            errs.append(rel(z_h, z_r))
+        dz = padded(a.P, C, g)
+        g_r, g_h = padded(a.P, C, g), to_dev(padded(a.P, C, g), dev)
+        SPEC.relu_gate(dz, z_r, g_r)
+        K.relu_gate(to_dev(dz, dev), to_dev(z_r, dev), g_h)
+        errs.append(rel(g_h, g_r))
+        return max(errs), 1e-6
+    return run
+
+
+CASES += [
+    ("stem7 2x3x32x32", case_stem7(2, 32, 32)),
+    ("stem7 1x3x48x80", case_stem7(1, 48, 80)),
+    ("maxpool 2x16x16 C=64", case_maxpool(2, 16, 16, 64)),
+    ("maxpool 1x24x40 C=64", case_maxpool(1, 24, 40, 64)),
+    ("rows stride 2 C=256", case_rows_stride(2, 16, 16, 256, 2)),
+    ("rows stride 2 C=128 8x12", case_rows_stride(1, 8, 12, 128, 2)),
+    ("bottleneck tail C=256", case_bottleneck_tail(2, 16, 16, 256)),
+    ("bottleneck tail C=2048", case_bottleneck_tail(2, 4, 4, 2048)),
+    ("conv1x1 2048->512 (ResNet layer4)", case_conv(2, 8, 8, 2048, 512, 1, 1)),
+    ("conv3x3 512->512 dil4 (ResNet layer4)", case_conv(2, 8, 8, 512, 512, 3, 4)),
+    ("conv3x3 2048->256 dil6 (ResNet ASPP)", case_conv(2, 8, 8, 2048, 256, 3, 6, lazy=False)),
+    ("dgrad1x1 1024<-256", case_dgrad(2, 8, 8, 1024, 256, 1, 1, accumulate=True)),
+    ("wgrad1x1 1024->2048", case_wgrad(2, 8, 8, 1024, 2048, 1, 1)),
+    ("wgrad3x3 2048->256 dil6", case_wgrad(2, 8, 8, 2048, 256, 3, 6, lazy=False)),
+]

@@ -161,6 +161,55 @@ class SpecKernels:
         g = _nchw(dy, N, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
         dw.copy_(torch.nn.grad.conv2d_weight(x, dw.shape, g, 2, 1))
 
+    # ------------------------------------------------------------------ ResNet-101 pieces
+    def stem7_fwd(self, x, w, out, stats=None):
+        y = _rows(F.conv2d(x, w, None, 2, 3))
+        if stats is not None:
+            stats[0, 0] += y.double().sum(0)
+            stats[0, 1] += (y.double() ** 2).sum(0)
+        out.copy_(y)
+
+    def stem7_wgrad(self, x, dy, dw):
+        N, _, H, W = x.shape
+        g = _nchw(dy, N, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+        dw.copy_(torch.nn.grad.conv2d_weight(x, dw.shape, g, 2, 3))
+
+    def maxpool_fwd(self, src: Act, out, idx):
+        """MaxPool2d(3, 2, 1) of the transformed src; idx = winning tap kh*3+kw (first maximum)."""
+        u = _nchw(transform(src), src.N, src.H, src.W)
+        cols = F.unfold(F.pad(u, (1, 1, 1, 1), value=float("-inf")), 3, stride=2)      # [N, C*9, L]
+        cols = cols.reshape(src.N, src.C, 9, -1)
+        best = cols.max(2, keepdim=True).values
+        first = (cols == best).to(torch.uint8).argmax(2)                                # first index of the maximum
+        out.copy_(best[:, :, 0].permute(0, 2, 1).reshape(-1, src.C))
+        idx.copy_(first.permute(0, 2, 1).reshape(-1, src.C).to(torch.uint8))
+
+    def maxpool_bwd(self, dz, idx, N, H, W, out):
+        Cc = dz.shape[1]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        g = dz.reshape(N, Ho * Wo, Cc).permute(0, 2, 1)                                 # [N, C, L]
+        onehot = (idx.reshape(N, Ho * Wo, Cc).permute(0, 2, 1).unsqueeze(2).long() ==
+                  torch.arange(9, device=dz.device).view(1, 1, 9, 1)).to(dz.dtype)
+        cols = (onehot * g.unsqueeze(2)).reshape(N, Cc * 9, Ho * Wo)
+        full = F.fold(cols, (H + 2, W + 2), 3, stride=2)[:, :, 1:H + 1, 1:W + 1]
+        out.copy_(_rows(full))
+
+    def rows_stride(self, src, N, H, W, stride, out, scatter=False):
+        Cc = src.shape[1]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        if not scatter:
+            out.copy_(src.reshape(N, H, W, Cc)[:, ::stride, ::stride].reshape(-1, Cc))
+        else:
+            full = src.new_zeros(N, H, W, Cc)
+            full[:, ::stride, ::stride] = src.reshape(N, Ho, Wo, Cc)
+            out.copy_(full.reshape(-1, Cc))
+
+    def bn_add_relu(self, a: Act, b: Act, out):
+        out.copy_(torch.relu(transform(a) + transform(b)))
+
+    def relu_gate(self, dz, z, out):
+        out.copy_(torch.where(z > 0, dz, torch.zeros_like(dz)))
+
     # ------------------------------------------------------------------ batch norm pieces
     def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps,
                     scale, shift, mean, invstd):

@@ -55,9 +55,9 @@ def grads_ok(grads):
     return bad, gmean
 
 
-def seeded_model(seed=1337, perturb=False):
+def seeded_model(seed=1337, perturb=False, backbone="mobilenet"):
     torch.manual_seed(seed)
-    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True, freeze_bn=False,
+    m = DeepLab(num_classes=2, backbone=backbone, output_stride=16, sync_bn=True, freeze_bn=False,
                 method="prototype_full")
     if perturb:
         g = torch.Generator().manual_seed(5)
@@ -73,9 +73,9 @@ def seeded_model(seed=1337, perturb=False):
     return m
 
 
-def eval_parity(dev, B=2, S=64, perturb=True):
+def eval_parity(dev, B=2, S=64, perturb=True, backbone="mobilenet"):
     """HIP eval forward vs the oracle on the same weights; returns {output: rel err}."""
-    m = seeded_model(perturb=perturb).eval()
+    m = seeded_model(perturb=perturb, backbone=backbone).eval()
     sd = deeplab_ref.canonical_state(m.state_dict())
     x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
@@ -85,10 +85,11 @@ def eval_parity(dev, B=2, S=64, perturb=True):
     return {n: rel(a, b) for n, a, b in zip(NAMES, out, ref)}
 
 
-def train_parity(dev, B=2, S=64, extra_heads=True):
+def train_parity(dev, B=2, S=64, extra_heads=True, backbone="mobilenet"):
     """HIP training forward + backward (injected dropout masks) vs the fp64 oracle.  Returns
-    (forward errs vs fp32 oracle, {param: (err vs fp64, fp32-oracle err vs fp64)}, running-stat err)."""
-    m = seeded_model(perturb=True).train()
+    (forward errs vs fp32 oracle, {param: (err vs fp64, fp32-oracle err vs fp64)}, running-stat err,
+    {output: (err vs fp64, fp32-oracle err vs fp64)})."""
+    m = seeded_model(perturb=True, backbone=backbone).train()
     gen = torch.Generator().manual_seed(3)
     x = torch.randn(B, 3, S, S, generator=gen)
     tmap = (torch.rand(B, 2, S, S, generator=gen) > 0.5).float()
@@ -122,7 +123,8 @@ def train_parity(dev, B=2, S=64, extra_heads=True):
         g = live[k].grad
         grads[k] = (float("inf") if g is None else l2rel(g, o64[k].grad), l2rel(o32[k].grad, o64[k].grad))
     stats = max(rel(live[k], v) for k, v in o32.items() if k.endswith("running_mean") or k.endswith("running_var"))
-    return fwd, grads, stats
+    fwd64 = {n: (rel(a, c), rel(b, c)) for n, a, b, c in zip(NAMES, out, r32, r64)}
+    return fwd, grads, stats, fwd64
 
 
 def golden_parity(dev, tag):
@@ -131,7 +133,7 @@ def golden_parity(dev, tag):
     oracle-recovered dropout masks of the reference's own draw."""
     z = np.load(os.path.join(GOLDEN, "forward_%s.npz" % tag))
     B, S = int(z["B"]), int(z["S"])
-    m = seeded_model()
+    m = seeded_model(backbone="resnet" if tag.startswith("resnet") else "mobilenet")
     torch.manual_seed(int(z["input_seed"]))
     x = torch.randn(B, 3, S, S)
     errs = {}

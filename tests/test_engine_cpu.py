@@ -5,6 +5,7 @@ The HIP kernels themselves are checked against the same statements in the -m gpu
 import pytest
 import torch
 
+import model_cases
 from kernel_spec import SpecKernels
 from oracle import deeplab_ref, step_ref
 from uda_clr_amd.engine import GeneratorEngine
@@ -13,10 +14,10 @@ from uda_clr_amd.networks.deeplabv3 import DeepLab
 NAMES = ("x1", "x2", "feature", "x_bu_feature", "x_feature", "x1_before", "x2_before")
 
 
-def _model(seed=1337):
+def _model(seed=1337, backbone="mobilenet"):
     torch.manual_seed(seed)
-    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16)
-    m._engine_override = GeneratorEngine(SpecKernels())
+    m = DeepLab(num_classes=2, backbone=backbone, output_stride=16)
+    m._engine_override = GeneratorEngine(SpecKernels(), backbone=backbone)
     # perturb BN affine/running stats so that every term of the BN math is exercised
     g = torch.Generator().manual_seed(5)
     for k, v in m.state_dict().items():
@@ -35,9 +36,9 @@ def _rel(a, b):
     return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
 
 
-@pytest.mark.parametrize("size", [64, 96])
-def test_eval_forward_matches_oracle(size):
-    m = _model().eval()
+@pytest.mark.parametrize("size,backbone", [(64, "mobilenet"), (96, "mobilenet"), (64, "resnet"), (96, "resnet")])
+def test_eval_forward_matches_oracle(size, backbone):
+    m = _model(backbone=backbone).eval()
     x = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         mine = m(x)
@@ -47,8 +48,9 @@ def test_eval_forward_matches_oracle(size):
         assert _rel(a, b) < 2e-4, (n, _rel(a, b))
 
 
-def test_train_forward_backward_matches_oracle():
-    m = _model().train()
+@pytest.mark.parametrize("backbone", ["mobilenet", "resnet"])
+def test_train_forward_backward_matches_oracle(backbone):
+    m = _model(backbone=backbone).train()
     B, S = 2, 64
     gen = torch.Generator().manual_seed(3)
     x = torch.randn(B, 3, S, S, generator=gen)
@@ -84,21 +86,23 @@ def test_train_forward_backward_matches_oracle():
     for t, w in zip(r64[2:], wf64):
         l64 = l64 + 1e-2 * (t * w.view(1, -1, 1, 1)).pow(2).mean()
     l64.backward()
-    for n, a, b in zip(NAMES, outs, ref):
-        assert _rel(a, b) < 2e-4, (n, _rel(a, b))
-    assert abs(loss.item() - rloss.item()) < 1e-5 * abs(rloss.item())
+    # outputs: as close to the fp64 truth as the fp32 oracle is (training-mode BN over 2x4x4 samples
+    # through 100 layers of the ResNet amplifies fp32 rounding to 1e-3; MobileNetV2 stays at 1e-5)
+    for n, a, b, c in zip(NAMES, outs, ref, r64):
+        assert _rel(a, c) < 3.0 * _rel(b, c) + 2e-4, (n, _rel(a, c), _rel(b, c))
+    assert abs(loss.item() - l64.item()) < 3.0 * abs(rloss.item() - l64.item()) + 1e-5 * abs(l64.item())
     live = m._flat_state()
-    worst = ("", 0.0)
+    grads = {}
     for k in deeplab_ref.parameter_keys(osd):
         g = live[k].grad
         assert g is not None, k
-        e, floor = _rel(g, o64[k].grad), _rel(osd[k].grad, o64[k].grad)
-        worst = max(worst, (k, e / max(floor, 1e-4)), key=lambda t: t[1])
-        assert e < 3.0 * floor + 1e-4, (k, e, floor)
-    print("worst grad rel err", worst)
+        grads[k] = (model_cases.l2rel(g, o64[k].grad), model_cases.l2rel(osd[k].grad, o64[k].grad))
+    bad, gmean = model_cases.grads_ok(grads)
+    assert not bad, list(bad.items())[:10]
+    assert gmean < 1.5, gmean          # same arithmetic as the fp32 oracle up to summation order
     for k, v in osd.items():
         if k.endswith("running_mean") or k.endswith("running_var"):
-            assert _rel(live[k], v) < 5e-4, k
+            assert _rel(live[k], o64[k]) < 3.0 * _rel(v, o64[k]) + 5e-4, k
         if k.endswith("num_batches_tracked"):
             assert int(live[k]) == int(v) == 1
 

@@ -26,6 +26,23 @@ def test_state_dict_matches_reference_manifest(golden_dir):
     assert abs(float(sum(p.double().sum() for p in params)) - man["param_sum"]) < 1e-6
 
 
+def test_resnet_state_dict_matches_reference_manifest(golden_dir):
+    man = json.load(open(os.path.join(golden_dir, "manifest_resnet.json")))
+    torch.manual_seed(man["seed"])
+    m = DeepLab(num_classes=2, backbone="resnet", output_stride=16, sync_bn=True, freeze_bn=False,
+                method="prototype_full")
+    sd = m.state_dict()
+    assert len(sd) == man["n_state_keys"] == 687
+    assert list(sd.keys()) == [e["key"] for e in man["entries"]]
+    for e in man["entries"]:
+        v = sd[e["key"]]
+        assert list(v.shape) == e["shape"], e["key"]
+        assert abs(float(v.double().sum()) - e["sum"]) <= 1e-9 * max(1.0, abs(e["sum"])), e["key"]
+    assert sum(p.numel() for p in m.parameters()) == man["n_params"] == 59340391
+    n1, n10 = sum(1 for _ in m.get_1x_lr_params()), sum(1 for _ in m.get_10x_lr_params())
+    assert n1 + n10 == man["n_param_tensors"]
+
+
 def test_cpu_forward_fails_loudly():
     import pytest
     m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16)

@@ -175,6 +175,67 @@ extern "C" int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t
     return 0;
 }
 
+// Bottleneck output (resnet.py:37-41):  out = relu(ta(a) + tb(b)),  ta/tb the pending per-channel
+// transforms of the two branches (bn3 of the main path; identity or the shortcut's BN).
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(uda_src_t a, uda_src_t b, float* __restrict__ out,
+                                                          int64_t ldo, int64_t P) {
+    const int C = a.C, cblk0 = blockIdx.y * RED_CBLK;
+    const int Cb = min(RED_CBLK, C - cblk0), G = (Cb + 3) >> 2, PP = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
+    if (pl >= PP) return;
+    const int c0 = cblk0 + cg * 4;
+    Xf4 xa, xb;
+    uda_load_xf4(xa, a.scale, a.shift, c0, C);
+    uda_load_xf4(xb, b.scale, b.shift, c0, C);
+    const int64_t base = (int64_t)blockIdx.x * (PP * EW_ITER);
+#pragma unroll 4
+    for (int it = 0; it < EW_ITER; ++it) {
+        const int64_t p = base + (int64_t)it * PP + pl;
+        if (p >= P) break;
+        const float4 av = uda_ld4(a.x + p * a.ldx + c0), bv = uda_ld4(b.x + p * b.ldx + c0);
+        const float va[4] = {av.x, av.y, av.z, av.w}, vb[4] = {bv.x, bv.y, bv.z, bv.w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = fmaxf(uda_act(va[j] * xa.sc[j] + xa.sh[j], a.act) + uda_act(vb[j] * xb.sc[j] + xb.sh[j], b.act), 0.f);
+        st4_guard(out + p * ldo + c0, v, C - c0);
+    }
+}
+
+extern "C" int uda_bn_add_relu(const uda_src_t* a, const uda_src_t* b, float* out, int64_t ldo, void* stream) {
+    if (int e = src_check(a, "uda_bn_add_relu")) return e;
+    if (int e = src_check(b, "uda_bn_add_relu")) return e;
+    UDA_REQUIRE(a->C == b->C && a->N == b->N && a->H == b->H && a->W == b->W && !a->mask && !b->mask,
+                "uda_bn_add_relu: operands must have one shape and no masks");
+    UDA_REQUIRE(out && uda_aligned16(out) && ldo % 4 == 0 && ldo >= a->C, "uda_bn_add_relu: bad out");
+    const int64_t P = (int64_t)a->N * a->H * a->W;
+    hipLaunchKernelGGL(bn_add_relu_kernel, ew_grid2(P, a->C), dim3(256), 0, (hipStream_t)stream, *a, *b, out, ldo, P);
+    UDA_LAUNCH_CHECK("bn_add_relu");
+    return 0;
+}
+
+// backward of that ReLU: g = dz where the stored block output z is positive
+__global__ __launch_bounds__(256) void relu_gate_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ z,
+                                                        int64_t ldz, int64_t P, int C4, float* __restrict__ out, int64_t ldo) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= P * C4) return;
+    const int64_t p = e / C4;
+    const int c0 = (int)(e % C4) * 4;
+    const float4 g = uda_ld4(dz + p * lddz + c0), v = uda_ld4(z + p * ldz + c0);
+    uda_st4(out + p * ldo + c0, make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f,
+                                            v.w > 0.f ? g.w : 0.f));
+}
+
+extern "C" int uda_relu_gate(const float* dz, int64_t lddz, const float* z, int64_t ldz, int64_t P, int C, float* out,
+                             int64_t ldo, void* stream) {
+    UDA_REQUIRE(dz && z && out && P > 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 &&
+                    uda_aligned16(dz) && uda_aligned16(z) && uda_aligned16(out), "uda_relu_gate: bad args (C %% 4 == 0, aligned rows)");
+    hipLaunchKernelGGL(relu_gate_kernel, dim3(uda_cdiv(P * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
+                       P, C / 4, out, ldo);
+    UDA_LAUNCH_CHECK("relu_gate");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // generic [P, C] column reductions.  MODE 0: (sum x [, sum x^2]);  MODE 1: BN backward sums.
 struct RedArgs {

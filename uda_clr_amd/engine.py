@@ -1,4 +1,4 @@
-"""Execution plan of the DeepLabV3+/MobileNetV2 generator on the HIP kernels.
+"""Execution plan of the DeepLabV3+ generator (MobileNetV2 or ResNet-101 backbone) on the HIP kernels.
 
 The whole generator is ONE autograd node (``networks.deeplabv3._GeneratorFn``): this module runs
 its forward as a fixed sequence of kernel launches on NHWC buffers and its backward as the
@@ -11,6 +11,7 @@ Reference behaviour reproduced (file:line in /root/reference):
                                          1x1 expand conv, so the expand BN's statistics run over
                                          (H+2d)(W+2d) positions and the depthwise conv sees
                                          relu6(shift) on its border
+  networks/backbone/resnet.py:23-43,113-124   Bottleneck / ResNet.forward (BASELINE.json configs[4])
   networks/aspp.py:65-78, networks/decoder.py:45-56
 
 Fusion scheme ("kernels"): every conv writes its raw output once and accumulates the
@@ -92,18 +93,51 @@ class _Ctx:
         self.bnlog = []          # (prefix, BNRec) of every training-mode BN of this forward
 
 
+def resnet_plan(output_stride: int = 16, layers=(3, 4, 23)):
+    """[(prefix, inplanes, planes, stride, dilation, has_downsample)] per Bottleneck (resnet.py:47-111)."""
+    if output_stride == 16:
+        strides, dils = (1, 2, 2, 1), (1, 1, 1, 2)
+    elif output_stride == 8:
+        strides, dils = (1, 2, 1, 1), (1, 1, 2, 4)
+    else:
+        raise NotImplementedError
+    plan, inp = [], 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256), layers), start=1):
+        for b in range(n):
+            st = strides[li - 1] if b == 0 else 1
+            plan.append(("backbone.layer%d.%d" % (li, b), inp, planes, st, dils[li - 1],
+                         b == 0 and (st != 1 or inp != 4 * planes)))
+            inp = 4 * planes
+    for b, mg in enumerate((1, 2, 4)):
+        st = strides[3] if b == 0 else 1
+        plan.append(("backbone.layer4.%d" % b, inp, 512, st, mg * dils[3], b == 0 and (st != 1 or inp != 2048)))
+        inp = 2048
+    return plan
+
+
 class GeneratorEngine:
-    def __init__(self, kernels, output_stride: int = 16, seed: int = 1337):
+    def __init__(self, kernels, output_stride: int = 16, seed: int = 1337, backbone: str = "mobilenet"):
         self.K = kernels
         self.os = output_stride
-        self.blocks = block_plan(output_stride)
+        self.backbone = backbone
         self.dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
         self.seed = seed
         self.rng_offset = 0
-        # channels that receive BN statistics in one forward (stem, 17 blocks, ASPP, decoder)
-        n = 32
-        for inp, oup, stride, dil, t in self.blocks:
-            n += (inp * t if t != 1 else 0) + inp * t + oup
+        # channels that receive BN statistics in one forward (stem, blocks, ASPP, decoder)
+        if backbone == "mobilenet":
+            self.blocks = block_plan(output_stride)
+            self.c_high, self.c_low = 320, 24
+            n = 32
+            for inp, oup, stride, dil, t in self.blocks:
+                n += (inp * t if t != 1 else 0) + inp * t + oup
+        elif backbone == "resnet":
+            self.rblocks = resnet_plan(output_stride)
+            self.c_high, self.c_low = 2048, 256
+            n = 64
+            for pre, inp, planes, stride, dil, has_ds in self.rblocks:
+                n += 2 * planes + 4 * planes * (2 if has_ds else 1)
+        else:
+            raise NotImplementedError("backbone %r" % (backbone,))
         self.bn_channels = n + 5 * 256 + 256 + 48 + 256 + 256 + 305
 
     # ------------------------------------------------------------------ small helpers
@@ -164,19 +198,10 @@ class GeneratorEngine:
             self.rng_offset += 1
         return m, 1.0 / (1.0 - p)
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, params: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
-                need_grad: bool, masks=None):
-        K = self.K
-        ctx = _Ctx()
-        ctx.params, ctx.x = params, x
-        S = ctx.S
+    # ------------------------------------------------------------------ MobileNetV2 backbone
+    def _mobilenet_forward(self, ctx, x, training):
+        K, S, params = self.K, ctx.S, ctx.params
         N, _, Hin, Win = x.shape
-        if Hin % 16 or Win % 16:
-            raise ValueError("input height/width must be multiples of 16, got %dx%d" % (Hin, Win))
-        ctx.N = N
-        if training:
-            ctx.arena = _Arena(x, STAT_SLOTS * 2 * self.bn_channels)
         # ---- stem (mobilenet.py:8-13)
         H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
         y0 = self._buf(x, N * H * W, 32)
@@ -219,6 +244,184 @@ class GeneratorEngine:
             if i == 3:
                 low = a
         S["blocks"] = recs
+        return a, low
+
+    # ------------------------------------------------------------------ ResNet-101 backbone
+    def _resnet_forward(self, ctx, x, training):
+        """resnet.py:113-124.  The two stride-2 bottlenecks (layer2.0, layer3.0) run their 3x3 conv at
+        stride 1 on the MFMA kernel and keep every other pixel (4 % extra FLOPs of the backbone)."""
+        K, S, params = self.K, ctx.S, ctx.params
+        N, _, Hin, Win = x.shape
+        H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+        y0 = self._buf(x, N * H * W, 64)
+        st = self._stats(ctx, 64, training)
+        K.stem7_fwd(x, params["backbone.conv1.weight"], y0, st)
+        a0 = self._bn_act(ctx, "backbone.bn1", y0, N, H, W, st, N * H * W, training, ACT_RELU)
+        Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        z = self._buf(x, N * Hp * Wp, 64)
+        idx = torch.empty((N * Hp * Wp, 64), dtype=torch.uint8, device=x.device)
+        K.maxpool_fwd(a0, z, idx)
+        S["stem"] = dict(a0=a0, idx=idx)
+        a = Act(z, N, Hp, Wp)
+        recs, low = [], None
+        for pre, inp, planes, stride, dil, has_ds in self.rblocks:
+            zin, H, W = a, a.H, a.W
+            P = N * H * W
+            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+            Po = N * Ho * Wo
+            y1 = self._buf(x, P, planes)
+            st = self._stats(ctx, planes, training)
+            K.conv(zin, self._w(ctx, pre + ".conv1.weight", "ohwi"), 1, 1, y1, stats=st)
+            a1 = self._bn_act(ctx, pre + ".bn1", y1, N, H, W, st, P, training, ACT_RELU)
+            y2 = self._buf(x, Po, planes)
+            st = self._stats(ctx, planes, training)
+            if stride == 1:
+                K.conv(a1, self._w(ctx, pre + ".conv2.weight", "ohwi"), 3, dil, y2, stats=st)
+            else:
+                yfull = self._buf(x, P, planes)
+                K.conv(a1, self._w(ctx, pre + ".conv2.weight", "ohwi"), 3, dil, yfull)
+                K.rows_stride(yfull, N, H, W, stride, y2)
+                if training:
+                    K.colstats(y2, st)
+                del yfull
+            a2 = self._bn_act(ctx, pre + ".bn2", y2, N, Ho, Wo, st, Po, training, ACT_RELU)
+            y3 = self._buf(x, Po, 4 * planes)
+            st = self._stats(ctx, 4 * planes, training)
+            K.conv(a2, self._w(ctx, pre + ".conv3.weight", "ohwi"), 1, 1, y3, stats=st)
+            a3 = self._bn_act(ctx, pre + ".bn3", y3, N, Ho, Wo, st, Po, training, ACT_NONE)
+            zs = ad = None
+            if has_ds:
+                zs = zin
+                if stride != 1:
+                    zsb = self._buf(x, Po, inp)
+                    K.rows_stride(zin.x, N, H, W, stride, zsb)
+                    zs = Act(zsb, N, Ho, Wo)
+                yd = self._buf(x, Po, 4 * planes)
+                st = self._stats(ctx, 4 * planes, training)
+                K.conv(zs, self._w(ctx, pre + ".downsample.0.weight", "ohwi"), 1, 1, yd, stats=st)
+                ad = self._bn_act(ctx, pre + ".downsample.1", yd, N, Ho, Wo, st, Po, training, ACT_NONE)
+            zo = self._buf(x, Po, 4 * planes)
+            K.bn_add_relu(a3, ad if has_ds else zin, zo)
+            a = Act(zo, N, Ho, Wo)
+            recs.append(dict(pre=pre, stride=stride, dil=dil, zin=zin, a1=a1, a2=a2, a3=a3, zs=zs, ad=ad, zo=a))
+            if pre.endswith("layer1.2"):
+                low = a
+        S["rblocks"] = recs
+        return a, low
+
+    def _resnet_backward(self, ctx, G, d_z, d_low):
+        """d_z: gradient w.r.t. the [P16, 2048] backbone output, d_low: w.r.t. the layer1 output."""
+        K, S, x = self.K, ctx.S, ctx.x
+        N = ctx.N
+        for r in reversed(S["rblocks"]):
+            pre, stride, dil = r["pre"], r["stride"], r["dil"]
+            zin, a1, a2, a3, zs, ad, zo = r["zin"], r["a1"], r["a2"], r["a3"], r["zs"], r["ad"], r["zo"]
+            H, W, Ho, Wo = zin.H, zin.W, zo.H, zo.W
+            if pre.endswith("layer1.2"):
+                d_z.add_(d_low)
+            g = self._buf(x, zo.P, zo.C)
+            K.relu_gate(d_z, zo.x, g)
+            del d_z
+            dy3 = self._buf(x, zo.P, zo.C)
+            self._bn_backward(ctx, G, a3, g, out=dy3)
+            self._wgrad(ctx, G, pre + ".conv3.weight", a2, dy3, 1, 1)
+            dU2 = self._buf(x, a2.P, a2.C)
+            self._dgrad(ctx, pre + ".conv3.weight", dy3, N, Ho, Wo, 1, 1, dU2)
+            del dy3
+            dy2 = self._bn_backward(ctx, G, a2, dU2)
+            if stride != 1:
+                full = self._buf(x, a1.P, a2.C)
+                K.rows_stride(dy2, N, H, W, stride, full, scatter=True)
+                dy2 = full
+            self._wgrad(ctx, G, pre + ".conv2.weight", a1, dy2, 3, dil)
+            dU1 = self._buf(x, a1.P, a1.C)
+            self._dgrad(ctx, pre + ".conv2.weight", dy2, N, H, W, 3, dil, dU1)
+            del dU2, dy2
+            dy1 = self._bn_backward(ctx, G, a1, dU1)
+            self._wgrad(ctx, G, pre + ".conv1.weight", zin, dy1, 1, 1)
+            d_zin = self._buf(x, zin.P, zin.C)
+            if ad is not None:
+                dyd = self._bn_backward(ctx, G, ad, g)
+                self._wgrad(ctx, G, pre + ".downsample.0.weight", zs, dyd, 1, 1)
+                if stride == 1:
+                    self._dgrad(ctx, pre + ".downsample.0.weight", dyd, N, H, W, 1, 1, d_zin)
+                else:
+                    d_zs = self._buf(x, zs.P, zs.C)
+                    self._dgrad(ctx, pre + ".downsample.0.weight", dyd, N, Ho, Wo, 1, 1, d_zs)
+                    K.rows_stride(d_zs, N, H, W, stride, d_zin, scatter=True)
+                    del d_zs
+                self._dgrad(ctx, pre + ".conv1.weight", dy1, N, H, W, 1, 1, d_zin, addend=d_zin)
+            else:
+                self._dgrad(ctx, pre + ".conv1.weight", dy1, N, H, W, 1, 1, d_zin, addend=g)
+            del g, dU1, dy1
+            d_z = d_zin
+        st = S["stem"]
+        a0 = st["a0"]
+        dU0 = self._buf(x, a0.P, 64)
+        K.maxpool_bwd(d_z, st["idx"], N, a0.H, a0.W, dU0)
+        dy0 = self._bn_backward(ctx, G, a0, dU0)
+        dw0 = torch.empty_like(ctx.params["backbone.conv1.weight"])
+        K.stem7_wgrad(x, dy0, dw0)
+        G["backbone.conv1.weight"] = dw0
+
+    def _mobilenet_backward(self, ctx, G, d_a, d_low):
+        K, S, x = self.K, ctx.S, ctx.x
+        N = ctx.N
+        # ---- backbone, last block first (mobilenet.py:61-67)
+        d_z = d_a
+        dU_stem = None
+        for i in range(len(S["blocks"]), 0, -1):
+            r = S["blocks"][i - 1]
+            pre, t, stride, dil = r["pre"], r["t"], r["stride"], r["dil"]
+            kd, kdb, kp, kpb = r["keys"]
+            zin, e, d, pb = r["zin"], r["e"], r["d"], r["pb"]
+            No, Ho, Wo = d.N, d.H, d.W
+            Hi, Wi = zin.H, zin.W
+            dyp = self._buf(x, d.P, pb.C)
+            self._bn_backward(ctx, G, pb, d_z, out=dyp)
+            self._wgrad(ctx, G, pre + kp + ".weight", d, dyp, 1, 1)
+            dUd = self._buf(x, d.P, d.C)
+            self._dgrad(ctx, pre + kp + ".weight", dyp, No, Ho, Wo, 1, 1, dUd)
+            dyd = self._bn_backward(ctx, G, d, dUd)
+            dwg = torch.empty_like(ctx.params[pre + kd + ".weight"])
+            K.dwconv_wgrad(e, dyd, stride, dil, r["border"], dwg)
+            G[pre + kd + ".weight"] = dwg
+            dUe = self._buf(x, zin.P, d.C)
+            K.dwconv_dgrad(dyd, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, N, Hi, Wi, dUe)
+            del dUd, dyd, dyp
+            if t != 1:
+                dye = self._bn_backward(ctx, G, e, dUe)
+                self._wgrad(ctx, G, pre + ".conv.0.weight", zin, dye, 1, 1)
+                d_zin = self._buf(x, zin.P, zin.C)
+                addend = d_z if r["use_res"] else (d_low if i == 4 else None)
+                self._dgrad(ctx, pre + ".conv.0.weight", dye, N, Hi, Wi, 1, 1, d_zin, addend=addend)
+                d_z = d_zin
+                del dUe, dye
+            else:
+                dU_stem = dUe
+        # ---- stem (mobilenet.py:8-13); the image itself needs no gradient
+        dy0 = self._bn_backward(ctx, G, S["stem"], dU_stem)
+        dw0 = torch.empty_like(ctx.params["backbone.features.0.0.weight"])
+        K.stem_wgrad(x, dy0, dw0)
+        G["backbone.features.0.0.weight"] = dw0
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, params: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
+                need_grad: bool, masks=None):
+        K = self.K
+        ctx = _Ctx()
+        ctx.params, ctx.x = params, x
+        S = ctx.S
+        N, _, Hin, Win = x.shape
+        if Hin % 16 or Win % 16:
+            raise ValueError("input height/width must be multiples of 16, got %dx%d" % (Hin, Win))
+        ctx.N = N
+        if training:
+            ctx.arena = _Arena(x, STAT_SLOTS * 2 * self.bn_channels)
+        if self.backbone == "mobilenet":
+            a, low = self._mobilenet_forward(ctx, x, training)
+        else:
+            a, low = self._resnet_forward(ctx, x, training)
         # ---- ASPP (aspp.py:65-78): branches write channel windows of one [P, 1280] buffer
         a17, H16, W16 = a, a.H, a.W
         P16 = N * H16 * W16
@@ -233,7 +436,7 @@ class GeneratorEngine:
                    cat[:, sl], stats=st)
             brecs.append(self._bn(ctx, key + ".bn", st, P16, training, coef[0, sl], coef[1, sl],
                                   coef[2, sl], coef[3, sl]))
-        gp = self._empty(x, N, 320)
+        gp = self._empty(x, N, self.c_high)
         K.gap_fwd(a17.x, N, gp, 1.0 / (H16 * W16))
         yg = self._empty(x, N, 256)
         st = self._stats(ctx, 256, training)
@@ -472,7 +675,7 @@ class GeneratorEngine:
         dylo = self._empty(x, P4, 48)
         self._bn_backward(ctx, G, lo, d_xf[:, 256:304], out=dylo)
         self._wgrad(ctx, G, "decoder.conv1.weight", low, dylo, 1, 1)
-        d_low = self._buf(x, P4, 24)
+        d_low = self._buf(x, P4, self.c_low)
         self._dgrad(ctx, "decoder.conv1.weight", dylo, N, H4, W4, 1, 1, d_low)
         # ---- bilinear x4 of the ASPP output (decoder.py:50)
         d_feat = self._empty(x, P16, 256)
@@ -497,9 +700,9 @@ class GeneratorEngine:
                   BNRec("aspp.global_avg_pool.2", coef[2, 1024:], coef[3, 1024:], float(N)))
         dyg = self._bn_backward(ctx, G, yga, dUg)
         self._wgrad(ctx, G, "aspp.global_avg_pool.1.weight", A["gpa"], dyg, 1, 1)
-        d_gp = self._empty(x, N, 320)
+        d_gp = self._empty(x, N, self.c_high)
         self._dgrad(ctx, "aspp.global_avg_pool.1.weight", dyg, N, 1, 1, 1, 1, d_gp)
-        d_a = self._empty(x, P16, 320)
+        d_a = self._empty(x, P16, self.c_high)
         K.broadcast_rows(d_gp, N, d_a, 1.0 / (H16 * W16), None)
         a17 = A["a17"]
         for j, dl in enumerate(self.dils, start=1):
@@ -509,41 +712,8 @@ class GeneratorEngine:
             self._wgrad(ctx, G, key, a17, dyc[:, sl], k, dl)
             self._dgrad(ctx, key, dyc[:, sl], N, H16, W16, k, dl, d_a, addend=d_a)
         del dUc, dyc
-        # ---- backbone, last block first (mobilenet.py:61-67)
-        d_z = d_a
-        dU_stem = None
-        for i in range(len(S["blocks"]), 0, -1):
-            r = S["blocks"][i - 1]
-            pre, t, stride, dil = r["pre"], r["t"], r["stride"], r["dil"]
-            kd, kdb, kp, kpb = r["keys"]
-            zin, e, d, pb = r["zin"], r["e"], r["d"], r["pb"]
-            No, Ho, Wo = d.N, d.H, d.W
-            Hi, Wi = zin.H, zin.W
-            dyp = self._buf(x, d.P, pb.C)
-            self._bn_backward(ctx, G, pb, d_z, out=dyp)
-            self._wgrad(ctx, G, pre + kp + ".weight", d, dyp, 1, 1)
-            dUd = self._buf(x, d.P, d.C)
-            self._dgrad(ctx, pre + kp + ".weight", dyp, No, Ho, Wo, 1, 1, dUd)
-            dyd = self._bn_backward(ctx, G, d, dUd)
-            dwg = torch.empty_like(ctx.params[pre + kd + ".weight"])
-            K.dwconv_wgrad(e, dyd, stride, dil, r["border"], dwg)
-            G[pre + kd + ".weight"] = dwg
-            dUe = self._buf(x, zin.P, d.C)
-            K.dwconv_dgrad(dyd, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, N, Hi, Wi, dUe)
-            del dUd, dyd, dyp
-            if t != 1:
-                dye = self._bn_backward(ctx, G, e, dUe)
-                self._wgrad(ctx, G, pre + ".conv.0.weight", zin, dye, 1, 1)
-                d_zin = self._buf(x, zin.P, zin.C)
-                addend = d_z if r["use_res"] else (d_low if i == 4 else None)
-                self._dgrad(ctx, pre + ".conv.0.weight", dye, N, Hi, Wi, 1, 1, d_zin, addend=addend)
-                d_z = d_zin
-                del dUe, dye
-            else:
-                dU_stem = dUe
-        # ---- stem (mobilenet.py:8-13); the image itself needs no gradient
-        dy0 = self._bn_backward(ctx, G, S["stem"], dU_stem)
-        dw0 = torch.empty_like(ctx.params["backbone.features.0.0.weight"])
-        K.stem_wgrad(x, dy0, dw0)
-        G["backbone.features.0.0.weight"] = dw0
+        if self.backbone == "mobilenet":
+            self._mobilenet_backward(ctx, G, d_a, d_low)
+        else:
+            self._resnet_backward(ctx, G, d_a, d_low)
         return G

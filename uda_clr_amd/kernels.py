@@ -57,6 +57,14 @@ SYMBOLS = {
     "uda_stem_workspace_bytes": (_U, [_L]),
     "uda_stem_fwd": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P]),
     "uda_stem_wgrad": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
+    "uda_stem7_workspace_bytes": (_U, [_L]),
+    "uda_stem7_fwd": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P]),
+    "uda_stem7_wgrad": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _U, _P]),
+    "uda_maxpool_fwd": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
+    "uda_maxpool_bwd": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
+    "uda_rows_stride": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "uda_bn_add_relu": (_I, [C.POINTER(UdaSrc), C.POINTER(UdaSrc), _P, _L, _P]),
+    "uda_relu_gate": (_I, [_P, _L, _P, _L, _L, _I, _P, _L, _P]),
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "uda_bn_running_replay": (_I, [_P, _P, _I, _D, _I, _F, _F, _P, _P, _P]),
     "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
@@ -264,6 +272,67 @@ class HipKernels:
         ws = self._ws(dy, self.lib.uda_stem_workspace_bytes(Po))
         self._ck(self.lib.uda_stem_wgrad(x.data_ptr(), N, H, W, g, ldg, dw.data_ptr(), ws.data_ptr(), ws.numel(),
                                          self._stream()))
+
+    # ------------------------------------------------------------------ ResNet-101 pieces
+    def stem7_fwd(self, x, w, out, stats=None):
+        self._dev(x)
+        N, c3, H, W = x.shape
+        assert c3 == 3 and x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (64, 3, 7, 7)
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        assert out.shape == (Po, 64)
+        y, ldy = _mat(out, "out")
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, 64)
+        self._ck(self.lib.uda_stem7_fwd(x.data_ptr(), N, H, W, w.data_ptr(), y, ldy, _ptr(stats), self._stream()))
+
+    def stem7_wgrad(self, x, dy, dw):
+        N, _, H, W = x.shape
+        Po = N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        assert dy.shape == (Po, 64) and dw.is_contiguous() and dw.numel() == 64 * 147
+        g, ldg = _mat(dy, "dy")
+        ws = self._ws(dy, self.lib.uda_stem7_workspace_bytes(Po))
+        self._ck(self.lib.uda_stem7_wgrad(x.data_ptr(), N, H, W, g, ldg, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          self._stream()))
+
+    def maxpool_fwd(self, src: Act, out, idx):
+        s = self._src(src)
+        Po = src.N * ((src.H - 1) // 2 + 1) * ((src.W - 1) // 2 + 1)
+        assert out.shape == (Po, src.C) and idx.shape == (Po, src.C) and idx.dtype == torch.uint8
+        o, ldo = _mat(out, "out")
+        i, ldi = _mat(idx, "idx")
+        self._ck(self.lib.uda_maxpool_fwd(C.byref(s), o, ldo, i, ldi, self._stream()))
+
+    def maxpool_bwd(self, dz, idx, N, H, W, out):
+        Cc = dz.shape[1]
+        assert out.shape == (N * H * W, Cc) and idx.shape == dz.shape
+        g, ldg = _mat(dz, "dz")
+        i, ldi = _mat(idx, "idx")
+        o, ldo = _mat(out, "out")
+        self._ck(self.lib.uda_maxpool_bwd(g, ldg, i, ldi, N, H, W, Cc, o, ldo, self._stream()))
+
+    def rows_stride(self, src, N, H, W, stride, out, scatter=False):
+        """scatter=False: out[(n,oh,ow)] = src[(n,oh*s,ow*s)] (src is the H x W side); scatter=True: the
+        transpose, out is the H x W side and receives zeros between the samples."""
+        Cc = src.shape[1]
+        Po = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
+        big, small = (out, src) if scatter else (src, out)
+        assert big.shape == (N * H * W, Cc) and small.shape == (Po, Cc)
+        a, lda = _mat(src, "src")
+        o, ldo = _mat(out, "out")
+        self._ck(self.lib.uda_rows_stride(a, lda, N, H, W, Cc, stride, int(scatter), o, ldo, self._stream()))
+
+    def bn_add_relu(self, a: Act, b: Act, out):
+        sa, sb = self._src(a), self._src(b)
+        assert out.shape == a.x.shape == b.x.shape
+        o, ldo = _mat(out, "out")
+        self._ck(self.lib.uda_bn_add_relu(C.byref(sa), C.byref(sb), o, ldo, self._stream()))
+
+    def relu_gate(self, dz, z, out):
+        assert dz.shape == z.shape == out.shape
+        g, ldg = _mat(dz, "dz")
+        v, ldv = _mat(z, "z")
+        o, ldo = _mat(out, "out")
+        self._ck(self.lib.uda_relu_gate(g, ldg, v, ldv, dz.shape[0], dz.shape[1], o, ldo, self._stream()))
 
     # ------------------------------------------------------------------ batch norm
     def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, invstd):

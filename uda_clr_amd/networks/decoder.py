@@ -8,10 +8,11 @@ from ._tree import Holder, child, conv, kaiming_bn_init
 class Decoder(Holder):
     def __init__(self, num_classes, backbone, method, BatchNorm):
         super().__init__()
-        if backbone != 'mobilenet':
-            raise NotImplementedError("decoder is built for the mobilenet backbone (24 low-level channels)")
+        if backbone not in ('mobilenet', 'resnet'):
+            raise NotImplementedError("decoder is built for the mobilenet (24) and resnet (256) low-level widths")
+        low = 24 if backbone == 'mobilenet' else 256             # decoder.py:11-16
         self.method = method
-        child(self, "conv1", conv(24, 48, 1))
+        child(self, "conv1", conv(low, 48, 1))
         child(self, "bn1", BatchNorm(48))
         child(self, "last_conv.0", BatchNorm(305))
         child(self, "last_conv.3", conv(305, num_classes, 1, bias=True))

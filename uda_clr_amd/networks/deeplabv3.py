@@ -1,4 +1,5 @@
-"""DeepLabV3+ generator - the drop-in for the reference's ``networks/deeplabv3.py``.
+"""DeepLabV3+ generator (MobileNetV2 or ResNet-101 backbone) - the drop-in for the reference's
+``networks/deeplabv3.py``.
 
 Same constructor, same ``state_dict`` keys (675 entries incl. the aliased backbone slices), same
 seeded initialisation, same 7-tuple from ``forward`` (deeplabv3.py:32-41):
@@ -53,6 +54,7 @@ class DeepLab(Holder):
             raise NotImplementedError("the fused heads are built for num_classes=2 (cup, disc)")
         BatchNorm = nn.BatchNorm2d
         self.output_stride = output_stride
+        self.backbone_name = backbone
         self.backbone = build_backbone(backbone, output_stride, BatchNorm)
         self.aspp = build_aspp(backbone, output_stride, BatchNorm)
         self.decoder = build_decoder(num_classes, backbone, method, BatchNorm)
@@ -78,7 +80,7 @@ class DeepLab(Holder):
                             yield p
 
     def get_1x_lr_params(self):
-        return self._lr_params([self.backbone.features])
+        return self._lr_params([self.backbone.features if self.backbone_name == 'mobilenet' else self.backbone])
 
     def get_10x_lr_params(self):
         return self._lr_params([self.aspp, self.decoder])
@@ -117,8 +119,9 @@ class DeepLab(Holder):
 
     def _flat_state(self):
         sd = {}
-        for name, mod in (("backbone.features", self.backbone.features), ("aspp", self.aspp),
-                          ("decoder", self.decoder)):
+        bb = ("backbone.features", self.backbone.features) if self.backbone_name == 'mobilenet' \
+            else ("backbone", self.backbone)
+        for name, mod in (bb, ("aspp", self.aspp), ("decoder", self.decoder)):
             for k, v in mod.named_parameters(prefix=name):
                 sd[k] = v
             for k, v in mod.named_buffers(prefix=name):
@@ -142,7 +145,7 @@ class DeepLab(Holder):
                                "%s tensor (there is no CPU fallback)" % x.device)
         if self._engine is None:
             from ..kernels import HipKernels
-            self._engine = GeneratorEngine(HipKernels(), self.output_stride)
+            self._engine = GeneratorEngine(HipKernels(), self.output_stride, backbone=self.backbone_name)
         return self._engine
 
     def forward(self, input):

@@ -399,8 +399,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn"]
     if "rn" in which:        # ResNet-101 variant (BASELINE.json configs[4]); pretrained fetch patched out (8c)
         mr = make_manifest("resnet", "manifest_resnet.json")
-        make_forward(mr, 2, 64, "resnet_64")
         make_forward(mr, 2, 128, "resnet_128")
+        make_forward(mr, 2, 256, "resnet_256")     # 16x16 maps in layer3/4: BN statistics over 512 samples
         del mr
         if which == ["rn"]:
             raise SystemExit(0)

@@ -591,8 +591,7 @@ def case_stem7(N, H, W, seed=16):
         dw_r, dw_h = torch.empty(64, 3, 7, 7), torch.empty(64, 3, 7, 7, device=dev)
         SPEC.stem7_wgrad(x, dy, dw_r)
         K.stem7_wgrad(x.to(dev), to_dev(dy, dev), dw_h)
-        DETAIL.update(y=rel(y_h, y_r), stats=rel(st_h.sum(0), st_r.sum(0)), dw=rel(dw_h, dw_r))
-        return max(DETAIL.values()), 3e-5
+        return max(rel(y_h, y_r), rel(st_h.sum(0), st_r.sum(0)), rel(dw_h, dw_r)), 3e-5
     return run
 
 
@@ -610,8 +609,7 @@ def case_maxpool(N, H, W, C, seed=17):
         du_r, du_h = padded(N * H * W, C, g), to_dev(padded(N * H * W, C, g), dev)
         SPEC.maxpool_bwd(dz, i_r, N, H, W, du_r)
         K.maxpool_bwd(to_dev(dz, dev), i_h, N, H, W, du_h)
-        DETAIL.update(z=rel(z_h, z_r), idx=float((i_h.cpu() != i_r).sum()), du=rel(du_h, du_r))
-        return max(DETAIL.values()), 1e-6
+        return max(rel(z_h, z_r), float((i_h.cpu() != i_r).sum()), rel(du_h, du_r)), 1e-6
     return run
 
 

@@ -230,6 +230,18 @@ def main():
                        "last_step_losses": losses},
             "roofline": timer.summary(),
         }
+        # step-level figures of SURVEY.md 8(d): algorithmic GFLOP / GB per counted image (reference algorithm,
+        # i.e. the 4 MC passes counted as full forwards although the fast path recomputes only their stochastic tail)
+        gflop = {("mobilenet", "source_only"): 158.2, ("mobilenet", "prototype_full"): 478.0,
+                 ("resnet", "source_only"): 531.0}.get((args.backbone, args.workload))
+        if gflop is not None:
+            tf = line["value"] / world * gflop / 1e3
+            line["step_roofline"] = {"algorithmic_gflop_per_image": gflop, "achieved_tflops_per_gpu": round(tf, 2),
+                                     "mfma_frac": round(tf / 157.3, 4)}
+            if (args.backbone, args.workload) == ("mobilenet", "source_only"):
+                gbs = line["value"] / world * 1.39
+                line["step_roofline"].update(algorithmic_gb_per_image=1.39, achieved_gb_s_per_gpu=round(gbs, 1),
+                                             hbm_frac=round(gbs / 8000.0, 4))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size, args.backbone)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-kernel totals of the TIMED steps of a `rocprofv3 --kernel-trace` run of bench.py.
+
+    python profiles/summarize_trace.py <..._kernel_trace.csv> --marker stem_fwd_kernel --per-step 2 --warmup 2 --steps 5
+
+The trace is cut at the first launch of `marker` that belongs to the first timed step (bench.py's warm-up
+steps hold MIOpen's one-off solver search for the stock-torch discriminators); `--per-step` = launches of the
+marker kernel per step (prototype_full: 2 grad-mode generator forwards; source_only: 1)."""
+import argparse
+import collections
+import csv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--marker", default="stem_fwd_kernel")
+    ap.add_argument("--per-step", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--top", type=int, default=60)
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
+    first = marks[a.warmup * a.per_step]
+    rows = rows[first:]
+    tot, cnt = collections.Counter(), collections.Counter()
+    for s, e, n in rows:
+        tot[n] += e - s
+        cnt[n] += 1
+    total = sum(tot.values())
+    print("kernel time %.1f ms/step, %d dispatches/step" % (total / 1e6 / a.steps, len(rows) // a.steps))
+    print("%-90s %6s %9s %9s %6s" % ("kernel", "calls", "ms/step", "avg_us", "%"))
+    for n, t in tot.most_common(a.top):
+        print("%-90s %6d %9.2f %9.1f %6.1f" % (n[:90], cnt[n], t / 1e6 / a.steps, t / 1e3 / cnt[n], 100.0 * t / total))
+
+
+if __name__ == "__main__":
+    main()

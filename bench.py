@@ -54,7 +54,7 @@ class ConvTimer:
 
     def __init__(self, kernels):
         self.k, self.orig = kernels, kernels.conv
-        self.events, self.flops, self.enabled = [], [], False
+        self.events, self.flops, self.bytes, self.enabled = [], [], [], False
         kernels.conv = self._conv
 
     def _conv(self, src, w, ksize, dil, out, bias=None, addend=None, stats=None):
@@ -67,17 +67,33 @@ class ConvTimer:
             e1.record()
             self.events.append((e0, e1))
             self.flops.append(2.0 * src.P * out.shape[1] * 9 * src.C)      # algorithmic: 2*P*Cout*9*Cin
+            self.bytes.append(4.0 * (src.P * (src.C + out.shape[1]) + out.shape[1] * 9 * src.C))   # in + out + weights, once each
 
-    def summary(self):
+    def summary(self, traffic=None):
+        """traffic: measured HBM bytes per launch (rocprofv3 PMC passes, profiles/*_traffic.json) or None."""
         if not self.events:
             return None
         ms = [a.elapsed_time(b) for a, b in self.events]
         tf = sum(self.flops) / (sum(ms) * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_gb_per_launch": round(sum(self.bytes) / len(ms) / 1e9, 4),
                 "kernel": "igemm_conv_ws_kernel<3,*,*> (3x3 implicit GEMM: forward + input-gradient of the decoder and ASPP convs)",
                 "launches": len(ms), "avg_launch_ms": round(sum(ms) / len(ms), 4),
                 "algorithmic_gflop_per_launch": round(sum(self.flops) / len(ms) / 1e9, 2)}
+
+
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS configuration
+    (profiles/r01_igemm_conv_ws_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, see profiles/pmc_traffic.py), in GB;
+    None for any other configuration (counters cannot be collected from inside the timed run)."""
+    if (args.workload, args.backbone, args.batch, args.size) != ("prototype_full", "mobilenet", 16, 512):
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_conv_ws_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["hbm_bytes_per_launch"] / 1e9, 4)
 
 
 def cpu_baseline(workload, B, S, backbone="mobilenet"):
@@ -228,7 +244,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc % fmt, "global_batch": per_step * world, "parallelism": "dp%d" % world,
                        "last_step_losses": losses},
-            "roofline": timer.summary(),
+            "roofline": timer.summary(measured_traffic(args)),
         }
         # step-level figures of SURVEY.md 8(d): algorithmic GFLOP / GB per counted image (reference algorithm,
         # i.e. the 4 MC passes counted as full forwards although the fast path recomputes only their stochastic tail)

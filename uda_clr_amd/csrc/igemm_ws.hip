@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
         st_ci = ci;
         int tapoff = 0;
         if (KS == 3) tapoff = ((t / 3 - 1) * W + (t % 3 - 1)) * a.dil;
+        if (a.debug & 16) tapoff = 0;      // diagnostics: every tap re-reads the centre pixel (cache-resident operand)
         if (XF >= 1) uda_load_xf4(xf, a.src.scale, a.src.shift, ci, kval ? C : 0);
         const int xoff = tapoff * (int)a.src.ldx + ci;
         const int moff = tapoff * (int)a.src.ldm + ci;

@@ -438,20 +438,41 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
         }
 }
 
-// dw[co][ci][t] = sum_s slab[s][co][t*Kc + ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int S, int Cout, int Cin, int T,
-                                    int Kc, float* __restrict__ dw) {
+// dw[co][ci][t] = sum_s slab[s][co][t*Kc + ci].  32 outputs x 8 split-lanes per workgroup: lane q sums the
+// slabs s = q, q+8, ... (4 loads in flight), the 8 partial sums meet in LDS in a fixed order (bitwise
+// reproducible).  The serial one-thread-per-output form took 38 us on the small layers (S up to 256).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int S, int Cout, int Cin, int T,
+                                                           int Kc, float* __restrict__ dw) {
+    __shared__ float red[8][33];
     const int64_t total = (int64_t)Cout * T * Cin;
     const int64_t stride = (int64_t)Cout * T * Kc;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(e % Cin);
-        const int t = (int)((e / Cin) % T);
-        const int co = (int)(e / ((int64_t)Cin * T));
-        const float* src = slab + ((int64_t)co * T + t) * Kc + ci;
+    const int ol = threadIdx.x & 31, q = threadIdx.x >> 5;
+    for (int64_t e0 = (int64_t)blockIdx.x * 32; e0 < total; e0 += (int64_t)gridDim.x * 32) {
+        const int64_t e = e0 + ol;
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += src[k * stride];
-        dw[((int64_t)co * Cin + ci) * T + t] = s;
+        int64_t dst = 0;
+        if (e < total) {
+            const int ci = (int)(e % Cin);
+            const int t = (int)((e / Cin) % T);
+            const int co = (int)(e / ((int64_t)Cin * T));
+            dst = ((int64_t)co * Cin + ci) * T + t;
+            const float* src = slab + ((int64_t)co * T + t) * Kc + ci;
+            int k = q;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (; k + 24 < S; k += 32) {
+                s0 += src[(int64_t)k * stride];
+                s1 += src[(int64_t)(k + 8) * stride];
+                s2 += src[(int64_t)(k + 16) * stride];
+                s3 += src[(int64_t)(k + 24) * stride];
+            }
+            for (; k < S; k += 8) s0 += src[(int64_t)k * stride];
+            s = (s0 + s1) + (s2 + s3);
+        }
+        red[q][ol] = s;
+        __syncthreads();
+        if (q == 0 && e < total)
+            dw[dst] = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
+        __syncthreads();
     }
 }
 
@@ -519,7 +540,7 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     UDA_LAUNCH_CHECK("igemm_wgrad");
     const int T = a->ksize * a->ksize;
     const int64_t total = (int64_t)a->Cout * T * a->src.C;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(uda_cdiv(total, 256) > 2048 ? 2048 : uda_cdiv(total, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(uda_cdiv(total, 32) > 4096 ? 4096 : uda_cdiv(total, 32)), dim3(256), 0, st,
                        k.slab, p.S, a->Cout, a->src.C, T, k.Kc, a->dw);
     UDA_LAUNCH_CHECK("wgrad_reduce");
     return 0;

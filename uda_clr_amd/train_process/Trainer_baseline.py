@@ -15,7 +15,7 @@ import timeit
 import torch
 
 from ..parallel import FlatGradAllReduce
-from ._common import HipOps, TrainerBase, get_lr, nan_guard, progress, shard_loader, trange
+from ._common import HipOps, TrainerBase, get_lr, nan_guard, prefer_fused, progress, shard_loader, trange
 
 
 class Trainer(TrainerBase):
@@ -28,7 +28,7 @@ class Trainer(TrainerBase):
         self.cuda = cuda
         self.warmup_epoch = warmup_epoch
         self.model_gen = model_gen
-        self.optim_gen = optimizer_gen
+        self.optim_gen = prefer_fused(optimizer_gen)
         self.lr_gen = lr_gen
         self.lr_decrease_rate = lr_decrease_rate
         self.batch_size = batch_size

@@ -31,7 +31,7 @@ import torch
 import torch.nn.functional as F
 
 from ..parallel import FlatGradAllReduce
-from ._common import HipOps, TrainerBase, get_lr, nan_guard, progress, shard_loader, trange
+from ._common import HipOps, TrainerBase, get_lr, nan_guard, prefer_fused, progress, shard_loader, trange
 
 mseloss = torch.nn.MSELoss()
 
@@ -67,9 +67,9 @@ class Trainer(TrainerBase):
         self.aug_weight, self.src_reg_weight = aug_weight, src_reg_weight
         self.model_dis2 = model_uncertainty_dis
         self.model_dis = model_dis
-        self.optim_gen = optimizer_gen
-        self.optim_dis = optimizer_dis
-        self.optim_dis2 = optimizer_uncertainty_dis
+        self.optim_gen = prefer_fused(optimizer_gen)
+        self.optim_dis = prefer_fused(optimizer_dis)
+        self.optim_dis2 = prefer_fused(optimizer_uncertainty_dis)
         self.lr_gen = lr_gen
         self.lr_dis = lr_dis
         self.lr_decrease_rate = lr_decrease_rate

@@ -40,6 +40,23 @@ def now():
     return datetime.now(_TZ)
 
 
+def prefer_fused(optimizer):
+    """Ask a stock torch optimizer (the entry script builds Adam / SGD objects and hands them in) for its fused
+    multi-tensor step: one launch instead of ~40 `foreach` launches per step for the 186 generator tensors.
+    Only fresh optimizers over device parameters are switched (a resumed one keeps the layout of its state)."""
+    import torch
+    if not isinstance(optimizer, (torch.optim.Adam, torch.optim.SGD)) or len(optimizer.state) > 0:
+        return optimizer
+    for g in optimizer.param_groups:
+        if "fused" not in g or g.get("differentiable") or g.get("capturable"):
+            return optimizer
+        if not all(p.is_cuda and p.dtype == torch.float32 for p in g["params"]):
+            return optimizer
+    for g in optimizer.param_groups:
+        g["fused"], g["foreach"] = True, False
+    return optimizer
+
+
 def get_lr(optimizer):
     for g in optimizer.param_groups:
         return g['lr']

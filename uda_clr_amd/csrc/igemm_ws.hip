@@ -21,16 +21,26 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef UDA_WS_MATH_WAVES_EVEN
+#define UDA_WS_MATH_WAVES_EVEN 8      // math waves of the even-width tiles (TN = 2, 4)
+#endif
+
 // XF: 0 = raw operand, 1 = BN affine + activation, 2 = same + dropout keep-mask
-template <int KS, int XF, int TN>
-__global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
+// MW = number of math waves (4: one per SIMD, wave tile 64 x 32*TN; 8: two per SIMD, wave tile 64 x 16*TN, so
+// one math wave's fragment reads / waits are covered by the other's MFMAs); the 4 loader waves follow them.
+template <int KS, int XF, int TN, int MW>
+__global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs a) {
     constexpr int BM = 128, BN = 64 * TN, TM = 2;
+    constexpr int WNN = MW / 2;                    // math waves along N
+    constexpr int TNW = 2 * TN / WNN;              // 32-column blocks per math wave
+    static_assert(MW == 4 || (MW == 8 && TN % 2 == 0), "8 math waves need an even tile width");
+    constexpr int NTHR = (MW + 4) * 64;
     constexpr int B_IT = BN / 32;
     constexpr int TILE = (BM + BN) * IG_LD;        // floats per buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= 4;     // provably wave-uniform
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= MW;    // provably wave-uniform
     const int lid = uda_xcd_remap(blockIdx.x, a.nMt * a.nNt);
     const int mt = lid / a.nNt, nt = lid % a.nNt;
     const int H = a.src.H, W = a.src.W, C = a.src.C;
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
     // mask per pixel row); a K-chunk then costs ~6 VALU per operand row instead of a 64-bit
     // multiply + four compares.  (PMC on the first version: loader waves, not the MFMA pipe, set the
     // chunk time: 11.4k-13.6k cycles against 8.2k cycles of MFMA work.)
-    const int lt = tid & 255, lrow = lt >> 3, kv = (lt & 7) * 4;
+    const int lt = (tid - MW * 64) & 255, lrow = lt >> 3, kv = (lt & 7) * 4;
     int rowoff[4], rowoffm[4], boff[B_IT];
     unsigned vmask[4];
     float4 areg[4], breg[B_IT];
@@ -152,17 +162,17 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
     };
 
     // ------------------------------------------------------------------ math state
-    const int wm = (wave & 3) >> 1, wn = wave & 1;
-    const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TN) + (lane & 31);
+    const int wm = (wave / WNN) & 1, wn = wave % WNN;
+    const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TNW) + (lane & 31);
     const int koff = 4 * (lane >> 5);
 
     // ------------------------------------------------------------------ pipeline
     // The role branch is OUTERMOST (wave-uniform, scalar branch) so the register allocation is the
     // maximum of the two roles' live sets, not their sum; both roles execute the same number of
     // workgroup barriers.
-    float s1[TN], s2[TN];
+    float s1[TNW], s2[TNW];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < TNW; ++j) s1[j] = s2[j] = 0.f;
     if (loader) {
         issue();
         stage(smem);
@@ -176,11 +186,11 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
             __syncthreads();
         }
     } else {
-        f32x16 acc[TM][TN];
+        f32x16 acc[TM][TNW];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TNW; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         __syncthreads();
@@ -194,11 +204,11 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
             const float* Bs = As + BM * IG_LD;
             // operand fragments are double-buffered in registers: group g+1 is read from LDS while
             // the 8*TN MFMAs of group g run, so only the first read after the barrier is exposed
-            float4 af[2][TM], bf[2][TN];
+            float4 af[2][TM], bf[2][TNW];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[0][i] = uda_ld4(&As[(arow + 32 * i) * IG_LD + koff]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + koff]);
+            for (int j = 0; j < TNW; ++j) bf[0][j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + koff]);
 #pragma unroll
             for (int g = 0; g < IG_BK / 8; ++g) {
                 const int cur = g & 1, nxt = cur ^ 1;
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[nxt][i] = uda_ld4(&As[(arow + 32 * i) * IG_LD + (g + 1) * 8 + koff]);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + (g + 1) * 8 + koff]);
+                    for (int j = 0; j < TNW; ++j) bf[nxt][j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + (g + 1) * 8 + koff]);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
                         const float4 a4 = af[cur][i];
                         const float av = s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w;
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) {
+                        for (int j = 0; j < TNW; ++j) {
                             const float4 b4 = bf[cur][j];
                             const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
@@ -227,9 +237,9 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
         // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        const int colb = n0 + wn * (32 * TN) + (lane & 31);
+        const int colb = n0 + wn * (32 * TNW) + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TNW; ++j) {
             const int col = colb + 32 * j;
             const bool cok = col < a.Cout;
             const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
@@ -253,11 +263,11 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
         float* red = smem;   // [2 (wm)][2][BN]
         if (!loader) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TNW; ++j) {
                 const float t1 = s1[j] + __shfl_xor(s1[j], 32);
                 const float t2 = s2[j] + __shfl_xor(s2[j], 32);
                 if (lane < 32) {
-                    const int cl = wn * (32 * TN) + 32 * j + lane;
+                    const int cl = wn * (32 * TNW) + 32 * j + lane;
                     red[(wm * 2 + 0) * BN + cl] = t1;
                     red[(wm * 2 + 1) * BN + cl] = t2;
                 }
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
         }
         __syncthreads();
         double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
-        for (int e = tid; e < 2 * BN; e += 512) {
+        for (int e = tid; e < 2 * BN; e += NTHR) {
             const int qd = e / BN, cl = e % BN;
             if (n0 + cl < a.Cout)
                 atomicAdd(&dst[qd * a.Cout + n0 + cl], (double)(red[(0 * 2 + qd) * BN + cl] + red[(1 * 2 + qd) * BN + cl]));
@@ -276,9 +286,10 @@ __global__ __launch_bounds__(512) void igemm_conv_ws_kernel(ConvKArgs a) {
 template <int KS, int XF, int TN>
 static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BN = 64 * TN;
+    constexpr int MW = (TN % 2 == 0) ? UDA_WS_MATH_WAVES_EVEN : 4;
     constexpr size_t lds = 2 * (128 + BN) * IG_LD * sizeof(float);
     static bool configured = false;
-    auto fn = igemm_conv_ws_kernel<KS, XF, TN>;
+    auto fn = igemm_conv_ws_kernel<KS, XF, TN, MW>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return uda_set_error("igemm_conv_ws: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -288,7 +299,7 @@ static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     k.nNt = uda_cdiv(k.Cout, BN);
     static const int dbg = getenv("UDA_WS_DEBUG") ? atoi(getenv("UDA_WS_DEBUG")) : 0;
     k.debug = dbg;
-    hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3(512), lds, st, k);
+    hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3((MW + 4) * 64), lds, st, k);
     UDA_LAUNCH_CHECK("igemm_conv_ws");
     return 0;
 }

@@ -666,3 +666,10 @@ CASES += [
     ("wgrad1x1 1024->2048", case_wgrad(2, 8, 8, 1024, 2048, 1, 1)),
     ("wgrad3x3 2048->256 dil6", case_wgrad(2, 8, 8, 2048, 256, 3, 6, lazy=False)),
 ]
+
+# 256-pixel workgroup tiles of the wide-tile kernel (taken when >= 512 of them exist: P >= 131072 at Cout = 256)
+CASES += [
+    ("conv3x3 32->256 P=131580 (256x256 tiles, ragged) relu mask", case_conv(2, 255, 258, 32, 256, 3, 1, mask=True)),
+    ("conv1x1 200->256 P=131072 (256x256 tiles) bias addend", case_conv(2, 256, 256, 200, 256, 1, 1, bias=True, addend=True)),
+    ("conv3x3 24->250 P=131072 dil2 (256x256 tiles) raw", case_conv(2, 256, 256, 24, 250, 3, 2, lazy=False)),
+]

@@ -28,13 +28,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // XF: 0 = raw operand, 1 = BN affine + activation, 2 = same + dropout keep-mask
 // MW = number of math waves (4: one per SIMD, wave tile 64 x 32*TN; 8: two per SIMD, wave tile 64 x 16*TN, so
 // one math wave's fragment reads / waits are covered by the other's MFMAs); the 4 loader waves follow them.
-template <int KS, int XF, int TN, int MW>
+// BM = 256 (8 math waves as 4 x 2, wave tile 64 x 32*TN): a third less staging per MFMA than BM = 128.
+template <int KS, int XF, int TN, int MW, int BM>
 __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs a) {
-    constexpr int BM = 128, BN = 64 * TN, TM = 2;
-    constexpr int WNN = MW / 2;                    // math waves along N
+    constexpr int BN = 64 * TN, TM = 2;
+    constexpr int WMM = BM / 64;                   // math waves along M
+    constexpr int WNN = MW / WMM;                  // math waves along N
     constexpr int TNW = 2 * TN / WNN;              // 32-column blocks per math wave
-    static_assert(MW == 4 || (MW == 8 && TN % 2 == 0), "8 math waves need an even tile width");
+    static_assert(WMM * WNN == MW && (2 * TN) % WNN == 0, "math-wave grid must tile the workgroup tile");
     constexpr int NTHR = (MW + 4) * 64;
+    constexpr int A_IT = BM / 32;
     constexpr int B_IT = BN / 32;
     constexpr int TILE = (BM + BN) * IG_LD;        // floats per buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -55,10 +58,10 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
     // multiply + four compares.  (PMC on the first version: loader waves, not the MFMA pipe, set the
     // chunk time: 11.4k-13.6k cycles against 8.2k cycles of MFMA work.)
     const int lt = (tid - MW * 64) & 255, lrow = lt >> 3, kv = (lt & 7) * 4;
-    int rowoff[4], rowoffm[4], boff[B_IT];
-    unsigned vmask[4];
-    float4 areg[4], breg[B_IT];
-    uint32_t amask[4];
+    int rowoff[A_IT], rowoffm[A_IT], boff[B_IT];
+    unsigned vmask[A_IT];
+    float4 areg[A_IT], breg[B_IT];
+    uint32_t amask[A_IT];
     unsigned aok = 0;
     Xf4 xf;
     int st_ci = 0;               // channel of the staged registers' first element
@@ -66,7 +69,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
     if (loader) {
         const int ldx = (int)a.src.ldx, ldm = (int)a.src.ldm;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_IT; ++i) {
             const int64_t p = m0 + lrow + 32 * i;
             const bool ok = p < P;
             const int q = ok ? (int)p : 0;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         const int moff = tapoff * (int)a.src.ldm + ci;
         aok = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_IT; ++i) {
             const bool ok = kval && ((vmask[i] >> (KS == 3 ? t : 0)) & 1u);
             areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             amask[i] = 0;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         const float ms = a.src.mask_scale;
         const bool ctail = (C & 3) != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_IT; ++i) {
             float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
             const bool ok = (aok >> i) & 1u;
 #pragma unroll
@@ -162,7 +165,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
     };
 
     // ------------------------------------------------------------------ math state
-    const int wm = (wave / WNN) & 1, wn = wave % WNN;
+    const int wm = (wave / WNN) % WMM, wn = wave % WNN;
     const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TNW) + (lane & 31);
     const int koff = 4 * (lane >> 5);
 
@@ -202,6 +205,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
             }
             const float* As = smem + (c & 1) * TILE;
             const float* Bs = As + BM * IG_LD;
+            if constexpr (BM == 128) {
             // operand fragments are double-buffered in registers: group g+1 is read from LDS while
             // the 8*TN MFMAs of group g run, so only the first read after the barrier is exposed
             float4 af[2][TM], bf[2][TNW];
@@ -233,6 +237,30 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
                     }
                 }
             }
+            } else {
+            // 168-VGPR budget (3 waves per SIMD, 128 accumulator registers): fragments single-buffered, the
+            // read latency of one math wave is covered by the MFMAs of the other math wave of the SIMD
+#pragma unroll
+            for (int g = 0; g < IG_BK / 8; ++g) {
+                float4 af[TM], bf[TNW];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = uda_ld4(&As[(arow + 32 * i) * IG_LD + g * 8 + koff]);
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) bf[j] = uda_ld4(&Bs[(brow + 32 * j) * IG_LD + g * 8 + koff]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j) {
+                            const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            }
             __syncthreads();
         }
         __builtin_amdgcn_s_setprio(0);
@@ -260,7 +288,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         }
     }
     if (a.stats) {           // uniform over the workgroup
-        float* red = smem;   // [2 (wm)][2][BN]
+        float* red = smem;   // [WMM][2][BN]
         if (!loader) {
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
@@ -277,25 +305,30 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
         for (int e = tid; e < 2 * BN; e += NTHR) {
             const int qd = e / BN, cl = e % BN;
-            if (n0 + cl < a.Cout)
-                atomicAdd(&dst[qd * a.Cout + n0 + cl], (double)(red[(0 * 2 + qd) * BN + cl] + red[(1 * 2 + qd) * BN + cl]));
+            if (n0 + cl < a.Cout) {
+                float t = 0.f;
+#pragma unroll
+                for (int m = 0; m < WMM; ++m) t += red[(m * 2 + qd) * BN + cl];
+                atomicAdd(&dst[qd * a.Cout + n0 + cl], (double)t);
+            }
         }
     }
 }
 
-template <int KS, int XF, int TN>
+template <int KS, int XF, int TN, int BM>
 static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BN = 64 * TN;
-    constexpr int MW = (TN % 2 == 0) ? UDA_WS_MATH_WAVES_EVEN : 4;
-    constexpr size_t lds = 2 * (128 + BN) * IG_LD * sizeof(float);
+    constexpr int MW = (BM == 256 || TN % 2 == 0) ? UDA_WS_MATH_WAVES_EVEN : 4;
+    constexpr size_t lds = 2 * (BM + BN) * IG_LD * sizeof(float);
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool configured = false;
-    auto fn = igemm_conv_ws_kernel<KS, XF, TN, MW>;
+    auto fn = igemm_conv_ws_kernel<KS, XF, TN, MW, BM>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return uda_set_error("igemm_conv_ws: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         configured = true;
     }
-    k.nMt = uda_cdiv(P, 128);
+    k.nMt = uda_cdiv(P, BM);
     k.nNt = uda_cdiv(k.Cout, BN);
     static const int dbg = getenv("UDA_WS_DEBUG") ? atoi(getenv("UDA_WS_DEBUG")) : 0;
     k.debug = dbg;
@@ -304,21 +337,21 @@ static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     return 0;
 }
 
-template <int KS, int TN>
+template <int KS, int TN, int BM>
 static int launch_ws_xf(ConvKArgs& k, int64_t P, hipStream_t st) {
-    if (k.src.mask) return launch_ws<KS, 2, TN>(k, P, st);
-    if (k.src.scale) return launch_ws<KS, 1, TN>(k, P, st);
-    if (k.src.act != ACT_NONE) return launch_ws<KS, 1, TN>(k, P, st);
-    return launch_ws<KS, 0, TN>(k, P, st);
+    if (k.src.mask) return launch_ws<KS, 2, TN, BM>(k, P, st);
+    if (k.src.scale) return launch_ws<KS, 1, TN, BM>(k, P, st);
+    if (k.src.act != ACT_NONE) return launch_ws<KS, 1, TN, BM>(k, P, st);
+    return launch_ws<KS, 0, TN, BM>(k, P, st);
 }
 
 template <int KS>
-static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, hipStream_t st) {
+static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, bool tall, hipStream_t st) {
     switch (tn) {
-        case 2: return launch_ws_xf<KS, 2>(k, P, st);
-        case 3: return launch_ws_xf<KS, 3>(k, P, st);
-        case 4: return launch_ws_xf<KS, 4>(k, P, st);
-        default: return launch_ws_xf<KS, 5>(k, P, st);
+        case 2: return launch_ws_xf<KS, 2, 128>(k, P, st);
+        case 3: return launch_ws_xf<KS, 3, 128>(k, P, st);
+        case 4: return tall ? launch_ws_xf<KS, 4, 256>(k, P, st) : launch_ws_xf<KS, 4, 128>(k, P, st);
+        default: return launch_ws_xf<KS, 5, 128>(k, P, st);
     }
 }
 
@@ -340,7 +373,10 @@ int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
             best = tn;
         }
     }
-    return k.ksize == 3 ? launch_ws_tn<3>(k, P, best, st) : launch_ws_tn<1>(k, P, best, st);
+    // 256-pixel tiles (a third less operand staging per MFMA) once they still fill the chip twice over
+    static const int tall_env = getenv("UDA_WS_TALL") ? atoi(getenv("UDA_WS_TALL")) : 1;
+    const bool tall = tall_env && best == 4 && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
+    return k.ksize == 3 ? launch_ws_tn<3>(k, P, best, tall, st) : launch_ws_tn<1>(k, P, best, tall, st);
 }
 
 // ==========================================================================================

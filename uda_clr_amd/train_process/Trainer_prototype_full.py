@@ -187,8 +187,16 @@ class Trainer(TrainerBase):
         self.optim_gen.zero_grad()
         self.optim_dis.zero_grad()
         self.optim_dis2.zero_grad()
-        self._set_requires_grad((dis, dis2), False)                                         # :266-271
+        # :266-271 freezes the discriminators for the generator step and re-runs them on the detached target
+        # outputs afterwards (:471-517).  Their weights do not change in between, so the target-side forward is
+        # run ONCE with a graph: the generator step back-propagates through it into the generator only
+        # (backward(inputs=...) prunes the discriminator weight gradients), the discriminator step re-uses its
+        # outputs with label 0 and back-propagates into the discriminator weights only.  Same values, two
+        # discriminator forwards per iteration fewer.
+        self._set_requires_grad((dis, dis2), True)
         self._set_requires_grad((gen,), True)
+        gen_params = [q for q in gen.parameters() if q.requires_grad]
+        dis_params = [q for m in (dis, dis2) for q in m.parameters()]
         imageS, target_map = self._to(sampleS['image']), self._to(sampleS['map'])
         target_boundary = self._to(sampleS['boundary'])
         imageT = self._to(sampleT['image'])
@@ -235,7 +243,7 @@ class Trainer(TrainerBase):
             loss_all = loss_all + (self.pro_weight * self.world) * intra_loss                # :465 (x world: see module doc)
             if self.src_reg:
                 loss_all = loss_all + self.src_reg_weight * self.loss_src_reg
-        loss_all.backward()
+        loss_all.backward(inputs=gen_params, retain_graph=True)
         if self.use_trg_cons and intra_loss is not None and self.retrify_pesudo:             # Appendix B (unpinned)
             # augmented consistency: pseudo labels of the clean target prediction supervise the prediction on
             # a photometrically augmented copy, on the pixels the MC-dropout std marked reliable
@@ -247,13 +255,13 @@ class Trainer(TrainerBase):
             self._reducers[0].all_reduce_mean()
         self.optim_gen.step()
         # ---- discriminators on detached generator outputs (:471-517)
-        self._set_requires_grad((dis, dis2), True)
         self._set_requires_grad((gen,), False)
-        oS, boundaryS, oT, boundaryT = oS.detach(), boundaryS.detach(), oT.detach(), boundaryT.detach()
+        oS, boundaryS = oS.detach(), boundaryS.detach()
         loss_D_same = self._adv(dis2(self._uncertainty(oS)), 1) + self._adv(dis(torch.sigmoid(boundaryS)), 1)
         loss_D_same.backward()
-        loss_D_diff = self._adv(dis2(self._uncertainty(oT)), 0) + self._adv(dis(torch.sigmoid(boundaryT)), 0)
-        loss_D_diff.backward()
+        loss_D_diff = self._adv(D_out1, 0) + self._adv(D_out2, 0)
+        loss_D_diff.backward(inputs=dis_params)
+        del D_out1, D_out2, loss_all
         if self._reducers is not None:
             self._reducers[1].all_reduce_mean()
             self._reducers[2].all_reduce_mean()

@@ -99,7 +99,7 @@ def measured_traffic(args):
 def cpu_baseline(workload, B, S, backbone="mobilenet"):
     """The oracle restatement of the same step on the host cores (bounded sample)."""
     from oracle import deeplab_ref, step_ref
-    from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
+    from oracle.gan_ref import BoundaryDiscriminator, UncertaintyDiscriminator
     from uda_clr_amd.networks.deeplabv3 import DeepLab
     torch.manual_seed(1337)
     sd = DeepLab(num_classes=2, backbone=backbone, output_stride=16).state_dict()

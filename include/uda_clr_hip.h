@@ -59,7 +59,7 @@ int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* st
 /* depthwise [C][1][3][3] -> [9][C] */
 int uda_relayout_dw(const float* w, int C, float* out, void* stream);
 
-/* ---- dense stride-1 convolution as FP32-MFMA implicit GEMM (1x1 and 3x3, any dilation).
+/* ---- dense stride-1 convolution as FP32-MFMA implicit GEMM (1x1, 3x3 with any dilation, and 2x2).
  * Replaces F.conv2d at mobilenet.py:43,49,57, aspp.py:50-53,56,59, decoder.py:20,32,33,37,41 and,
  * with uda_relayout_dgrad weights, their input-gradient.
  *   y[p,co] = bias[co] + addend[p,co] + sum_{t,ci} u(p+off_t, ci) * w[co][t][ci]
@@ -68,7 +68,10 @@ int uda_relayout_dw(const float* w, int C, float* out, void* stream);
 typedef struct uda_conv_args {
     uda_src_t src;
     const float* w;        /* [Cout][ksize*ksize][round4(src.C)] */
-    int32_t Cout, ksize, dil, _pad;
+    int32_t Cout, ksize, dil;
+    int32_t origin;        /* ksize 2 only: tap (kh,kw) reads pixel (h + kh - origin, w + kw - origin); 0 = the
+                              space-to-depth form of the 4x4 stride-2 convs of GAN.py:90-101, 1 = its input gradient.
+                              ksize 3 is centred (pad = dil), ksize 1 has one tap. */
     const float* bias;     /* [Cout] or NULL */
     const float* addend;   /* [P, ld_add] or NULL (may alias y) */
     int64_t ld_add;
@@ -83,7 +86,8 @@ typedef struct uda_wgrad_args {
     uda_src_t src;
     const float* dy;       /* [P, lddy] */
     int64_t lddy;
-    int32_t Cout, ksize, dil, _pad;
+    int32_t Cout, ksize, dil;
+    int32_t origin;        /* as in uda_conv_args_t */
     float* dw;             /* OIHW, contiguous */
     float* workspace;
     uint64_t workspace_bytes;
@@ -130,6 +134,17 @@ int uda_bn_add_relu(const uda_src_t* a, const uda_src_t* b, float* out, int64_t 
 /* its backward gate: out = dz where z > 0 else 0 */
 int uda_relu_gate(const float* dz, int64_t lddz, const float* z, int64_t ldz, int64_t P, int C, float* out,
                   int64_t ldo, void* stream);
+
+/* ---- patch discriminators (networks/GAN.py:86-148): Conv2d(4, stride 2, pad 2) = ksize-2
+ * uda_conv_fwd on the space-to-depth image z[n,i,j,(a,b,c)] = x[n, 2i+a-2, 2j+b-2, c] (zero outside the valid
+ * region valid_h x valid_w of the [N,Hs,Ws,C] source grid; Hz = (valid_h+5)/2).  uda_s2d_fwd also applies the
+ * previous layer's LeakyReLU (slope; 1 = none); uda_s2d_bwd routes dz back to the source grid (zeros outside
+ * the valid region), times the LeakyReLU gate read from the sign of z (z_sign NULL = no gate).
+ * nchw_*: the source side is an NCHW tensor (the discriminator input / its gradient). */
+int uda_s2d_fwd(const float* src, int64_t ld_src, int nchw_in, int N, int Hs, int Ws, int C, int valid_h,
+                int valid_w, float slope, float* z, int64_t ld_z, int Hz, int Wz, void* stream);
+int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, int Hz, int Wz, float slope, int N, int Hs,
+                int Ws, int C, int valid_h, int valid_w, float* dst, int64_t ld_dst, int nchw_out, void* stream);
 
 /* ---- batch-norm pieces (F.batch_norm, training and eval) */
 /* stats: double[UDA_STAT_SLOTS][2][C] */

@@ -83,7 +83,7 @@ def make_src(N, H, W, C, g, lazy=True, act=ACT_RELU, mask=False, bn=False, q1=Fa
 
 
 # ------------------------------------------------------------------------------------- cases
-def case_conv(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, bias=False, addend=False, stats=True, seed=0):
+def case_conv(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, bias=False, addend=False, stats=True, seed=0, origin=0):
     def run(dev):
         g = gen(seed)
         src = make_src(N, H, W, Cin, g, lazy, ACT_RELU6 if Cin % 8 else ACT_RELU, mask)
@@ -93,13 +93,13 @@ def case_conv(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, bias=False, add
         ad = padded(P, Cout, g) if addend else None
         out_r = padded(P, Cout, g)
         st_r = torch.zeros(16, 2, Cout, dtype=torch.float64) if stats else None
-        SPEC.conv(src, SPEC.relayout_ohwi(w), k, dil, out_r, b, ad, st_r)
+        SPEC.conv(src, SPEC.relayout_ohwi(w), k, dil, out_r, b, ad, st_r, origin=origin)
         K = hip()
         out_h = to_dev(padded(P, Cout, g), dev)
         st_h = torch.zeros(16, 2, Cout, dtype=torch.float64, device=dev) if stats else None
         wl = K.relayout_ohwi(w.to(dev))
         errs = [rel(wl, SPEC.relayout_ohwi(w))]
-        K.conv(act_to(src, dev), wl, k, dil, out_h, None if b is None else b.to(dev), to_dev(ad, dev), st_h)
+        K.conv(act_to(src, dev), wl, k, dil, out_h, None if b is None else b.to(dev), to_dev(ad, dev), st_h, origin=origin)
         errs.append(rel(out_h, out_r))
         if stats:
             errs.append(rel(st_h.sum(0), st_r.sum(0)))
@@ -132,15 +132,15 @@ def case_dgrad(N, H, W, Cin, Cout, k, dil, accumulate=False, seed=1):
     return run
 
 
-def case_wgrad(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, seed=2):
+def case_wgrad(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, seed=2, origin=0):
     def run(dev):
         g = gen(seed)
         src = make_src(N, H, W, Cin, g, lazy, ACT_RELU, mask)
         dy = padded(N * H * W, Cout, g)
         ref = torch.empty(Cout, Cin, k, k)
-        SPEC.conv_wgrad(src, dy, k, dil, ref)
+        SPEC.conv_wgrad(src, dy, k, dil, ref, origin=origin)
         out = torch.empty(Cout, Cin, k, k, device=dev)
-        hip().conv_wgrad(act_to(src, dev), to_dev(dy, dev), k, dil, out)
+        hip().conv_wgrad(act_to(src, dev), to_dev(dy, dev), k, dil, out, origin=origin)
         return rel(out, ref), 3e-5
     return run
 
@@ -672,4 +672,49 @@ CASES += [
     ("conv3x3 32->256 P=131580 (256x256 tiles, ragged) relu mask", case_conv(2, 255, 258, 32, 256, 3, 1, mask=True)),
     ("conv1x1 200->256 P=131072 (256x256 tiles) bias addend", case_conv(2, 256, 256, 200, 256, 1, 1, bias=True, addend=True)),
     ("conv3x3 24->250 P=131072 dil2 (256x256 tiles) raw", case_conv(2, 256, 256, 24, 250, 3, 2, lazy=False)),
+]
+
+
+# 2x2 taps (the space-to-depth form of the discriminators' 4x4 stride-2 convs, GAN.py:90-101)
+CASES += [
+    ("conv2x2 o0 8->64 (narrow) raw", case_conv(2, 18, 18, 8, 64, 2, 1, lazy=False, origin=0)),
+    ("conv2x2 o0 256->128 (wide)", case_conv(2, 19, 17, 256, 128, 2, 1, lazy=False, origin=0)),
+    ("conv2x2 o1 128->256 (wide, dgrad form) addend", case_conv(2, 19, 17, 128, 256, 2, 1, lazy=False, addend=True, origin=1)),
+    ("conv2x2 o0 2048->1", case_conv(2, 9, 9, 2048, 1, 2, 1, lazy=False, origin=0)),
+    ("wgrad2x2 o0 8->64", case_wgrad(2, 18, 18, 8, 64, 2, 1, lazy=False, origin=0)),
+    ("wgrad2x2 o0 256->128", case_wgrad(2, 19, 17, 256, 128, 2, 1, lazy=False, origin=0)),
+    ("wgrad2x2 o0 2048->1", case_wgrad(2, 9, 9, 2048, 1, 2, 1, lazy=False, origin=0)),
+]
+
+
+def case_s2d(N, H, W, C, nchw, vh=None, vw=None, seed=20):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        vh_, vw_ = vh or H, vw or W
+        Hz, Wz = (vh_ + 5) // 2, (vw_ + 5) // 2
+        src = torch.randn(N, C, H, W, generator=g) if nchw else padded(N * H * W, C, g)
+        z_r, z_h = padded(N * Hz * Wz, 4 * C, g), to_dev(padded(N * Hz * Wz, 4 * C, g), dev)
+        SPEC.s2d_fwd(src, nchw, N, H, W, C, vh_, vw_, 0.2, z_r)
+        K.s2d_fwd(src.to(dev) if nchw else to_dev(src, dev), nchw, N, H, W, C, vh_, vw_, 0.2, z_h)
+        errs = [rel(z_h, z_r)]
+        dz = torch.randn(N * Hz * Wz, 4 * C, generator=g)
+        zs = torch.randn(N * Hz * Wz, 4 * C, generator=g)
+        for sign in (None, zs):
+            if nchw:
+                d_r, d_h = torch.empty(N, C, H, W), torch.empty(N, C, H, W, device=dev)
+            else:
+                d_r, d_h = padded(N * H * W, C, g), to_dev(padded(N * H * W, C, g), dev)
+            SPEC.s2d_bwd(dz, sign, 0.2, N, H, W, C, vh_, vw_, d_r, nchw)
+            K.s2d_bwd(dz.to(dev), None if sign is None else sign.to(dev), 0.2, N, H, W, C, vh_, vw_, d_h, nchw)
+            errs.append(rel(d_h, d_r))
+        return max(errs), 0.0
+    return run
+
+
+CASES += [
+    ("s2d nchw C=1 32x32", case_s2d(2, 32, 32, 1, True)),
+    ("s2d nchw C=2 30x34", case_s2d(2, 30, 34, 2, True)),
+    ("s2d rows C=64 grid 18x18 valid 17x17", case_s2d(2, 18, 18, 64, False, 17, 17)),
+    ("s2d rows C=6 grid 11x9 valid 9x8 (scalar path)", case_s2d(1, 11, 9, 6, False, 9, 8)),
 ]

@@ -90,14 +90,24 @@ class SpecKernels:
         return w.reshape(w.shape[0], 9).t().contiguous()
 
     # ------------------------------------------------------------------ dense conv (stride 1)
-    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None):
+    @staticmethod
+    def _pad_taps(u, ksize, dil, origin):
+        """Zero padding that realises the tap geometry: ksize 3 centred (pad dil each side), ksize 2 with taps
+        (kh - origin, kw - origin): origin 0 reaches +1 (pad right/bottom), origin 1 reaches -1 (pad left/top)."""
+        if ksize == 3:
+            return F.pad(u, (dil, dil, dil, dil))
+        if ksize == 2:
+            return F.pad(u, (1, 0, 1, 0)) if origin else F.pad(u, (0, 1, 0, 1))
+        return u
+
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
         """out[p, co] = bias[co] + addend[p, co] + sum_{t, ci} u(p + off_t, ci) * w[co, t, ci];
-        ``w`` is [Cout, ksize^2, round4(Cin)]; zero padding dil*(ksize//2); stats (fp64 [2, Cout])
-        receives sum and sum of squares of the value before ``addend``."""
+        ``w`` is [Cout, ksize^2, round4(Cin)]; stats (fp64 [2, Cout]) receives sum and sum of squares of the
+        value before ``addend``."""
         Cin, Cout = src.C, out.shape[1]
-        u = _nchw(transform(src), src.N, src.H, src.W)
+        u = self._pad_taps(_nchw(transform(src), src.N, src.H, src.W), ksize, dil, origin)
         w4 = w[:, :, :Cin].reshape(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
-        y = _rows(F.conv2d(u, w4, bias, 1, dil * (ksize // 2), dil))
+        y = _rows(F.conv2d(u, w4, bias, 1, 0, dil if ksize == 3 else 1))
         if stats is not None:
             stats[0, 0] += y.double().sum(0)
             stats[0, 1] += (y.double() ** 2).sum(0)
@@ -105,12 +115,11 @@ class SpecKernels:
             y = y + addend
         out.copy_(y)
 
-    def conv_wgrad(self, src: Act, dy, ksize, dil, dw):
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
         """dw[co, ci, kh, kw] = sum_p dy[p, co] * u(p + off_t, ci)   (OIHW result)."""
-        u = _nchw(transform(src), src.N, src.H, src.W)
+        u = self._pad_taps(_nchw(transform(src), src.N, src.H, src.W), ksize, dil, origin)
         g = _nchw(dy, src.N, src.H, src.W)
-        pad = dil * (ksize // 2)
-        res = torch.nn.grad.conv2d_weight(u, dw.shape, g, 1, pad, dil)
+        res = torch.nn.grad.conv2d_weight(u, dw.shape, g, 1, 0, dil if ksize == 3 else 1)
         dw.copy_(res)
 
     # ------------------------------------------------------------------ depthwise 3x3
@@ -209,6 +218,30 @@ class SpecKernels:
 
     def relu_gate(self, dz, z, out):
         out.copy_(torch.where(z > 0, dz, torch.zeros_like(dz)))
+
+    # ------------------------------------------------------------------ patch-discriminator geometry
+    @staticmethod
+    def _s2d_grid(src, nchw, N, Hs, Ws, Cc):
+        return src if nchw else src.reshape(N, Hs, Ws, Cc).permute(0, 3, 1, 2)
+
+    def s2d_fwd(self, src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z):
+        """z[n,i,j,(a,b,c)] = leaky(x[n, 2i+a-2, 2j+b-2, c]) inside the valid vh x vw region, else 0."""
+        Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
+        x = self._s2d_grid(src, nchw, N, Hs, Ws, Cc)[:, :, :vh, :vw]
+        x = torch.where(x > 0, x, x * slope)
+        xp = F.pad(x, (2, 2 * Wz - vw - 2, 2, 2 * Hz - vh - 2))                       # [N, C, 2Hz, 2Wz]
+        zz = xp.reshape(N, Cc, Hz, 2, Wz, 2).permute(0, 2, 4, 3, 5, 1)               # n, i, j, a, b, c
+        z.copy_(zz.reshape(N * Hz * Wz, 4 * Cc))
+
+    def s2d_bwd(self, dz, z_sign, slope, N, Hs, Ws, Cc, vh, vw, dst, nchw):
+        Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
+        g = dz
+        if z_sign is not None:
+            g = torch.where(z_sign > 0, dz, dz * slope)
+        gp = g.reshape(N, Hz, Wz, 2, 2, Cc).permute(0, 5, 1, 3, 2, 4).reshape(N, Cc, 2 * Hz, 2 * Wz)
+        out = torch.zeros(N, Cc, Hs, Ws, dtype=dz.dtype, device=dz.device)
+        out[:, :, :vh, :vw] = gp[:, :, 2:2 + vh, 2:2 + vw]
+        dst.copy_(out if nchw else out.permute(0, 2, 3, 1).reshape(N * Hs * Ws, Cc))
 
     # ------------------------------------------------------------------ batch norm pieces
     def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps,

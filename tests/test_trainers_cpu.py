@@ -11,7 +11,7 @@ import torch
 from make_golden_inputs import synth_loader
 from oracle import deeplab_ref, step_ref
 from oracle_ops import OracleOps
-from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
+from oracle.gan_ref import BoundaryDiscriminator, UncertaintyDiscriminator   # CPU: the product's discriminators are HIP-only
 from uda_clr_amd.networks.deeplabv3 import DeepLab
 from uda_clr_amd.train_process import Trainer_baseline, Trainer_prototype_full
 

@@ -7,6 +7,7 @@ struct ConvKArgs {
     uda_src_t src;
     const float* w;
     int Cout, ksize, dil, Kc, Ktot;
+    int cen;       // tap (kh, kw) reads pixel offset ((kh - cen) * dil, (kw - cen) * dil): 1 for 3x3, 0|1 for 2x2
     const float* bias;
     const float* addend;
     int64_t ld_add;
@@ -22,6 +23,7 @@ struct WgradKArgs {
     const float* dy;
     int64_t lddy;
     int Cout, ksize, dil, Kc, Jtot;
+    int cen;
     float* slab;      // [S][Cout][Jtot]
     int nCot, nJt, chunks_per_split, nchunks;
 };

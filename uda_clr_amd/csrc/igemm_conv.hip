@@ -64,15 +64,16 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         const int k0 = chunk * IG_BK + kv;
         c_kval = k0 < a.Ktot;
         int t = 0, ci = k0;
-        if (a.ksize == 3) {
+        if (a.ksize >= 2) {
             t = k0 / a.Kc;
             ci = k0 - t * a.Kc;
         }
         c_ci = ci;
         int dh = 0, dw = 0;
-        if (a.ksize == 3) {
-            dh = (t / 3 - 1) * a.dil;
-            dw = (t % 3 - 1) * a.dil;
+        if (a.ksize >= 2) {
+            const int th = a.ksize == 3 ? t / 3 : t >> 1;
+            dh = (th - a.cen) * a.dil;
+            dw = (t - th * a.ksize - a.cen) * a.dil;
         }
         uda_load_xf4(xf, a.src.scale, a.src.shift, ci, c_kval ? C : 0);
         aok = 0;
@@ -265,7 +266,8 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(a != nullptr, "uda_conv_fwd: null args");
     if (int e = check_src(a->src, "uda_conv_fwd")) return e;
-    UDA_REQUIRE(a->ksize == 1 || a->ksize == 3, "uda_conv_fwd: ksize must be 1 or 3");
+    UDA_REQUIRE(a->ksize >= 1 && a->ksize <= 3, "uda_conv_fwd: ksize must be 1, 2 or 3");
+    UDA_REQUIRE(a->ksize != 2 || a->origin == 0 || a->origin == 1, "uda_conv_fwd: origin must be 0 or 1 for ksize 2");
     UDA_REQUIRE(a->Cout > 0 && a->dil >= 1 && a->y && a->w, "uda_conv_fwd: bad args");
     UDA_REQUIRE(uda_aligned16(a->w), "uda_conv_fwd: weights must be 16-byte aligned");
     UDA_REQUIRE(a->ldy >= a->Cout, "uda_conv_fwd: ldy < Cout");
@@ -276,6 +278,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.Cout = a->Cout;
     k.ksize = a->ksize;
     k.dil = a->dil;
+    k.cen = a->ksize == 3 ? 1 : (a->ksize == 2 ? a->origin : 0);
     k.Kc = ((a->src.C + 3) / 4) * 4;
     k.Ktot = a->ksize * a->ksize * k.Kc;
     k.bias = a->bias;
@@ -323,14 +326,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
     const int j0 = jt * BN + bjv;
     const bool jok = j0 < a.Jtot;
     int t = 0, ci = j0;
-    if (a.ksize == 3 && jok) {
+    if (a.ksize >= 2 && jok) {
         t = j0 / a.Kc;
         ci = j0 - t * a.Kc;
     }
     int dh = 0, dw = 0;
-    if (a.ksize == 3) {
-        dh = (t / 3 - 1) * a.dil;
-        dw = (t % 3 - 1) * a.dil;
+    if (a.ksize >= 2) {
+        const int th = a.ksize == 3 ? t / 3 : t >> 1;
+        dh = (th - a.cen) * a.dil;
+        dw = (t - th * a.ksize - a.cen) * a.dil;
     }
     Xf4 xf;
     uda_load_xf4(xf, a.src.scale, a.src.shift, ci, jok ? C : 0);
@@ -511,7 +515,8 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(a != nullptr, "uda_conv_wgrad: null args");
     if (int e = check_src(a->src, "uda_conv_wgrad")) return e;
-    UDA_REQUIRE(a->ksize == 1 || a->ksize == 3, "uda_conv_wgrad: ksize must be 1 or 3");
+    UDA_REQUIRE(a->ksize >= 1 && a->ksize <= 3, "uda_conv_wgrad: ksize must be 1, 2 or 3");
+    UDA_REQUIRE(a->ksize != 2 || a->origin == 0 || a->origin == 1, "uda_conv_wgrad: origin must be 0 or 1 for ksize 2");
     UDA_REQUIRE(a->dy && uda_aligned16(a->dy) && a->lddy % 4 == 0 && a->lddy >= ((a->Cout + 3) / 4) * 4,
                 "uda_conv_wgrad: dy must be 16-byte aligned with lddy %% 4 == 0 and >= round4(Cout)");
     const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
@@ -525,6 +530,7 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     k.Cout = a->Cout;
     k.ksize = a->ksize;
     k.dil = a->dil;
+    k.cen = a->ksize == 3 ? 1 : (a->ksize == 2 ? a->origin : 0);
     k.Kc = ((a->src.C + 3) / 4) * 4;
     k.Jtot = a->ksize * a->ksize * k.Kc;
     k.slab = a->workspace;

@@ -78,11 +78,12 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
             rowoffm[i] = q * ldm;
             unsigned vm = 0;
             if (ok) {
-                if (KS == 3) {
+                if (KS == 3) {          // multi-tap: 3x3 (9 taps) or 2x2 (4 taps), runtime a.ksize
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const int hh = ph + (t / 3 - 1) * a.dil, ww = pw + (t % 3 - 1) * a.dil;
-                        vm |= (hh >= 0 && hh < H && ww >= 0 && ww < W ? 1u : 0u) << t;
+                        const int th = a.ksize == 3 ? t / 3 : t / 2, tw = a.ksize == 3 ? t % 3 : t % 2;
+                        const int hh = ph + (th - a.cen) * a.dil, ww = pw + (tw - a.cen) * a.dil;
+                        vm |= (t < a.ksize * a.ksize && hh >= 0 && hh < H && ww >= 0 && ww < W ? 1u : 0u) << t;
                     }
                 } else {
                     vm = 1u;
@@ -103,10 +104,13 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
 
     auto issue = [&]() {       // loads of the chunk at (t_cur, ci_cur); then advance by BK
         const int t = t_cur, ci = ci_cur;
-        const bool kval = KS == 3 ? (t < 9) : (ci < a.Kc);
+        const bool kval = KS == 3 ? (t < a.ksize * a.ksize) : (ci < a.Kc);
         st_ci = ci;
         int tapoff = 0;
-        if (KS == 3) tapoff = ((t / 3 - 1) * W + (t % 3 - 1)) * a.dil;
+        if (KS == 3) {
+            const int th = a.ksize == 3 ? t / 3 : t >> 1;
+            tapoff = ((th - a.cen) * W + (t - th * a.ksize - a.cen)) * a.dil;
+        }
         if (a.debug & 16) tapoff = 0;      // diagnostics: every tap re-reads the centre pixel (cache-resident operand)
         if (XF >= 1) uda_load_xf4(xf, a.src.scale, a.src.shift, ci, kval ? C : 0);
         const int xoff = tapoff * (int)a.src.ldx + ci;
@@ -376,7 +380,7 @@ int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     // 256-pixel tiles (a third less operand staging per MFMA) once they still fill the chip twice over
     static const int tall_env = getenv("UDA_WS_TALL") ? atoi(getenv("UDA_WS_TALL")) : 1;
     const bool tall = tall_env && best == 4 && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
-    return k.ksize == 3 ? launch_ws_tn<3>(k, P, best, tall, st) : launch_ws_tn<1>(k, P, best, tall, st);
+    return k.ksize >= 2 ? launch_ws_tn<3>(k, P, best, tall, st) : launch_ws_tn<1>(k, P, best, tall, st);
 }
 
 // ==========================================================================================
@@ -409,8 +413,9 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     }
     int dh = 0, dw = 0;
     if (KS == 3) {
-        dh = (t / 3 - 1) * a.dil;
-        dw = (t % 3 - 1) * a.dil;
+        const int th = a.ksize == 3 ? t / 3 : t >> 1;
+        dh = (th - a.cen) * a.dil;
+        dw = (t - th * a.ksize - a.cen) * a.dil;
     }
     Xf4 xf;
     if (XF >= 1) uda_load_xf4(xf, a.src.scale, a.src.shift, ci, jok ? C : 0);
@@ -570,6 +575,6 @@ int launch_wgrad_ws(WgradKArgs& k, int S, hipStream_t st) {
     UDA_REQUIRE((P + 64) * k.src.ldx < lim && (P + 64) * k.lddy < lim && (P + 64) * (k.src.mask ? k.src.ldm : 1) < lim,
                 "uda_conv_wgrad: operand too large for the 32-bit element offsets of the wide-tile kernel");
     const int xf = k.src.mask ? 2 : ((k.src.scale || k.src.act != ACT_NONE) ? 1 : 0);
-    if (k.ksize == 3) return xf == 2 ? launch_wg<3, 2>(k, S, st) : xf == 1 ? launch_wg<3, 1>(k, S, st) : launch_wg<3, 0>(k, S, st);
+    if (k.ksize >= 2) return xf == 2 ? launch_wg<3, 2>(k, S, st) : xf == 1 ? launch_wg<3, 1>(k, S, st) : launch_wg<3, 0>(k, S, st);
     return xf == 2 ? launch_wg<1, 2>(k, S, st) : xf == 1 ? launch_wg<1, 1>(k, S, st) : launch_wg<1, 0>(k, S, st);
 }

@@ -1,0 +1,96 @@
+"""Execution plan of the patch discriminators (networks/GAN.py:86-148 of the reference) on the HIP kernels.
+
+Every layer is Conv2d(k=4, stride 2, pad 2, bias=False) followed (layers 1-4) by LeakyReLU(0.2).  The 4x4
+stride-2 convolution runs as a 2x2 stride-1 implicit GEMM (``uda_conv_fwd`` with ksize 2) on the space-to-depth
+image of the zero-padded input; ``uda_s2d_fwd`` builds that image and fuses the previous layer's LeakyReLU and the
+crop of its output grid, ``uda_s2d_bwd`` routes gradients back and applies the LeakyReLU gate.  Activations are
+NHWC matrices on the z grids (Hz = (H + 5) // 2: 258, 131, 67, 35, 19 for a 512 x 512 input); a layer's output
+lives on its own z grid with Ho = H // 2 + 1 valid rows/columns (257, 129, 65, 33, 17).
+
+``kernels`` is the binding object (HipKernels in the product; the tests' torch statement on CPU).
+"""
+from __future__ import annotations
+
+import torch
+
+from .acts import Act, round4
+
+SLOPE = 0.2
+
+
+def _zgrid(v):
+    return (v + 5) // 2
+
+
+class PatchDiscriminatorEngine:
+    def __init__(self, kernels):
+        self.K = kernels
+        self._wcache = {}
+
+    # z-space weight layouts of a [O, C, 4, 4] tensor, cached until the parameter changes
+    def _weights(self, w):
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._wcache.get(id(w))
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        O, Cc = w.shape[0], w.shape[1]
+        wz = w.detach().reshape(O, Cc, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(O, 4, 4 * Cc)   # o, (u,v), (a,b,c)
+        fwd = wz.contiguous()
+        dg = torch.zeros(4 * Cc, 4, round4(O), dtype=w.dtype, device=w.device)
+        dg[:, :, :O] = wz.flip(1).permute(2, 1, 0)                                                   # (a,b,c), flipped tap, o
+        self._wcache[id(w)] = (key, fwd, dg)
+        return fwd, dg
+
+    def forward(self, x, weights, need_grad):
+        """x: [N, C, H, W] (NCHW, as the reference feeds it).  Returns ([N, 1, Ho, Wo] logits, ctx)."""
+        K = self.K
+        N, Cc, H, W = x.shape
+        src, nchw, Hs, Ws, vh, vw, slope = x, True, H, W, H, W, 1.0
+        layers = []
+        for w in weights:
+            O = w.shape[0]
+            Hz, Wz = _zgrid(vh), _zgrid(vw)
+            z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
+            K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
+            y = torch.empty((N * Hz * Wz, round4(O)), dtype=torch.float32, device=x.device)[:, :O]
+            K.conv(Act(z, N, Hz, Wz), self._weights(w)[0], 2, 1, y, origin=0)
+            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw))
+            src, nchw, Hs, Ws, Cc, slope = y, False, Hz, Wz, O, SLOPE
+            vh, vw = vh // 2 + 1, vw // 2 + 1
+        out = src.reshape(N, Hs, Ws, Cc)[:, :vh, :vw].permute(0, 3, 1, 2)
+        return out, ((layers, N, tuple(x.shape)) if need_grad else None)
+
+    def backward(self, ctx, gout, weights, need_x, need_w):
+        """gout: gradient of the [N, 1, Ho, Wo] logits.  Returns (dx NCHW or None, [dw OIHW 4x4] or None)."""
+        K = self.K
+        layers, N, xshape = ctx
+        z5, C5, Hs5, Ws5, vh5, vw5, Hz, Wz, _ = layers[-1]
+        O = weights[-1].shape[0]
+        vh, vw = vh5 // 2 + 1, vw5 // 2 + 1
+        dy = torch.zeros((N, Hz, Wz, round4(O)), dtype=torch.float32, device=gout.device)
+        dy[:, :vh, :vw, :O] = gout.permute(0, 2, 3, 1)
+        dy = dy.reshape(N * Hz * Wz, round4(O))[:, :O]
+        dws = [None] * len(weights)
+        dx = None
+        for l in range(len(weights) - 1, -1, -1):
+            z, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw = layers[l]
+            w = weights[l]
+            O = w.shape[0]
+            if need_w:
+                dwz = torch.empty((O, 4 * Cc, 2, 2), dtype=torch.float32, device=z.device)
+                K.conv_wgrad(Act(z, N, Hz, Wz), dy, 2, 1, dwz, origin=0)
+                # [o, (a,b,c), u, v] -> [o, c, 2u+a, 2v+b]
+                dws[l] = dwz.reshape(O, 2, 2, Cc, 2, 2).permute(0, 3, 4, 1, 5, 2).reshape(O, Cc, 4, 4)
+            if l == 0 and not need_x:
+                break
+            dz = torch.empty_like(z)
+            K.conv(Act(dy, N, Hz, Wz), self._weights(w)[1], 2, 1, dz, origin=1)
+            if nchw:
+                dx = torch.empty(xshape, dtype=torch.float32, device=z.device)
+                K.s2d_bwd(dz, None, 1.0, N, Hs, Ws, Cc, vh, vw, dx, True)
+            else:
+                dyn = torch.empty((N * Hs * Ws, round4(Cc)), dtype=torch.float32, device=z.device)[:, :Cc]
+                K.s2d_bwd(dz, z, SLOPE, N, Hs, Ws, Cc, vh, vw, dyn, False)
+                dy = dyn
+            del dz
+        return dx, (dws if need_w else None)

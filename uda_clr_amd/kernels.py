@@ -29,13 +29,13 @@ class UdaSrc(C.Structure):
 
 class UdaConvArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("w", C.c_void_p), ("Cout", C.c_int32), ("ksize", C.c_int32),
-                ("dil", C.c_int32), ("_pad", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
+                ("dil", C.c_int32), ("origin", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
                 ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p)]
 
 
 class UdaWgradArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("dy", C.c_void_p), ("lddy", C.c_int64), ("Cout", C.c_int32),
-                ("ksize", C.c_int32), ("dil", C.c_int32), ("_pad", C.c_int32), ("dw", C.c_void_p),
+                ("ksize", C.c_int32), ("dil", C.c_int32), ("origin", C.c_int32), ("dw", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
@@ -65,6 +65,8 @@ SYMBOLS = {
     "uda_rows_stride": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "uda_bn_add_relu": (_I, [C.POINTER(UdaSrc), C.POINTER(UdaSrc), _P, _L, _P]),
     "uda_relu_gate": (_I, [_P, _L, _P, _L, _L, _I, _P, _L, _P]),
+    "uda_s2d_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _I, _I, _P]),
+    "uda_s2d_bwd": (_I, [_P, _P, _L, _I, _I, _F, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "uda_bn_running_replay": (_I, [_P, _P, _I, _D, _I, _F, _F, _P, _P, _P]),
     "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
@@ -190,8 +192,9 @@ class HipKernels:
         return out
 
     # ------------------------------------------------------------------ dense conv
-    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None):
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
         a = UdaConvArgs()
+        a.origin = origin
         a.src = self._src(src)
         Cout = out.shape[1]
         assert w.is_contiguous() and tuple(w.shape) == (Cout, ksize * ksize, round4(src.C)), \
@@ -212,8 +215,9 @@ class HipKernels:
         a.stats = _ptr(stats)
         self._ck(self.lib.uda_conv_fwd(C.byref(a), self._stream()))
 
-    def conv_wgrad(self, src: Act, dy, ksize, dil, dw):
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
         a = UdaWgradArgs()
+        a.origin = origin
         a.src = self._src(src)
         Cout = dy.shape[1]
         assert dy.shape[0] == src.P and dw.is_contiguous() and tuple(dw.shape) == (Cout, src.C, ksize, ksize)
@@ -333,6 +337,34 @@ class HipKernels:
         v, ldv = _mat(z, "z")
         o, ldo = _mat(out, "out")
         self._ck(self.lib.uda_relu_gate(g, ldg, v, ldv, dz.shape[0], dz.shape[1], o, ldo, self._stream()))
+
+    # ------------------------------------------------------------------ patch-discriminator geometry
+    def s2d_fwd(self, src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z):
+        """src: NCHW tensor (nchw=True) or [N*Hs*Ws, C] rows; z: [N*Hz*Wz, 4C] rows with Hz = (vh+5)//2."""
+        self._dev(src)
+        Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
+        assert z.shape == (N * Hz * Wz, 4 * Cc)
+        if nchw:
+            assert src.is_contiguous() and tuple(src.shape) == (N, Cc, Hs, Ws)
+            sp, lds_ = src.data_ptr(), 0
+        else:
+            assert src.shape == (N * Hs * Ws, Cc)
+            sp, lds_ = _mat(src, "src")
+        zp, ldz = _mat(z, "z")
+        self._ck(self.lib.uda_s2d_fwd(sp, lds_, int(nchw), N, Hs, Ws, Cc, vh, vw, float(slope), zp, ldz, Hz, Wz, self._stream()))
+
+    def s2d_bwd(self, dz, z_sign, slope, N, Hs, Ws, Cc, vh, vw, dst, nchw):
+        Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
+        assert dz.shape == (N * Hz * Wz, 4 * Cc) and (z_sign is None or (z_sign.shape == dz.shape and z_sign.stride(0) == dz.stride(0)))
+        gp, ldz = _mat(dz, "dz")
+        if nchw:
+            assert dst.is_contiguous() and tuple(dst.shape) == (N, Cc, Hs, Ws)
+            dp, ldd = dst.data_ptr(), 0
+        else:
+            assert dst.shape == (N * Hs * Ws, Cc)
+            dp, ldd = _mat(dst, "dst")
+        self._ck(self.lib.uda_s2d_bwd(gp, _ptr(z_sign), ldz, Hz, Wz, float(slope), N, Hs, Ws, Cc, vh, vw, dp, ldd, int(nchw),
+                                      self._stream()))
 
     # ------------------------------------------------------------------ batch norm
     def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, invstd):

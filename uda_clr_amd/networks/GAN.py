@@ -1,10 +1,38 @@
 """Patch discriminators of the adversarial branch - drop-in for ``networks/GAN.py:86-148``.
 
-Five 4x4 stride-2 pad-2 bias-free convolutions (1|2 -> 64 -> 128 -> 256 -> 512 -> 1) with
-LeakyReLU(0.2) between them, weights ~ N(0, 0.02).  They run on stock PyTorch-ROCm: SURVEY.md 8f-1
-ranks their native kernels as the first row AFTER the generator hot path.
+Five 4x4 stride-2 pad-2 bias-free convolutions (1|2 -> 64 -> 128 -> 256 -> 512 -> 1) with LeakyReLU(0.2)
+between them, weights ~ N(0, 0.02); same constructor, ``state_dict`` keys (``conv1.weight`` .. ``conv5.weight``)
+and seeded initialisation as the reference.  The ``nn.Conv2d`` children only hold the parameters: forward and
+backward are ONE autograd node executed by ``uda_clr_amd.gan_engine`` on the HIP kernels.
+There is no CPU path: a CPU input (or a missing ``libuda_clr_hip.so``) raises.
 """
+import torch
 import torch.nn as nn
+
+from ..gan_engine import PatchDiscriminatorEngine
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, need, *weights):
+        engine = module._engine_for(x)
+        out, ectx = engine.forward(x.contiguous().float(), weights, need)
+        ctx.engine, ctx.ectx, ctx.module, ctx.weights = engine, ectx, module, weights
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.ectx is None:
+            raise RuntimeError("discriminator forward ran without gradient bookkeeping")
+        mode = ctx.module.grad_mode
+        need_x = ctx.needs_input_grad[1] and mode in ("auto", "input")
+        need_w = any(ctx.needs_input_grad[3:]) and mode in ("auto", "weights")
+        dx, dws = ctx.engine.backward(ctx.ectx, gout, ctx.weights, need_x, need_w)
+        if mode != "input":
+            ctx.ectx = None
+        if dws is None:
+            dws = [None] * len(ctx.weights)
+        return (None, dx, None) + tuple(dws)
 
 
 class _PatchDiscriminator(nn.Module):
@@ -17,11 +45,31 @@ class _PatchDiscriminator(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 m.weight.data.normal_(0.0, 0.02)
+        self._engine = None
+        self._engine_override = None      # tests only: an engine bound to their torch kernel spec
+        # which gradients a backward pass through this module produces: "auto" = whatever autograd needs;
+        # "input" / "weights" let a training loop that back-propagates twice through ONE forward graph (generator
+        # step, then discriminator step) skip the half it is not going to use (autograd cannot prune inside a
+        # custom node).  The saved activations are released after an "auto" or "weights" pass.
+        self.grad_mode = "auto"
+
+    def _engine_for(self, x):
+        if self._engine_override is not None:
+            return self._engine_override
+        if not x.is_cuda:
+            raise RuntimeError("uda_clr_amd discriminators compute only on the MI355X HIP kernels; got a %s tensor "
+                               "(there is no CPU fallback)" % x.device)
+        if self._engine is None:
+            from ..kernels import HipKernels
+            self._engine = PatchDiscriminatorEngine(HipKernels())
+        return self._engine
 
     def forward(self, x):
-        for i in range(1, 5):
-            x = self.leakyrelu(getattr(self, "conv%d" % i)(x))
-        return self.conv5(x)
+        if x.dim() != 4 or x.shape[1] != self.conv1.weight.shape[1]:
+            raise ValueError("expected an [N, %d, H, W] batch" % self.conv1.weight.shape[1])
+        weights = [getattr(self, "conv%d" % i).weight for i in range(1, 6)]
+        need = torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights))
+        return _DiscFn.apply(self, x, need, *weights)
 
 
 class UncertaintyDiscriminator(_PatchDiscriminator):

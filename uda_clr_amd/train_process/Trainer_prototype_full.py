@@ -117,6 +117,12 @@ class Trainer(TrainerBase):
         return new, tuple(t.detach() for t in new)
 
     @staticmethod
+    def _grad_mode(models, mode):
+        for m in models:                      # the native discriminators' switch (networks/GAN.py); stock modules have none
+            if hasattr(m, "grad_mode"):
+                m.grad_mode = mode
+
+    @staticmethod
     def _set_requires_grad(models, flag):
         for m in models:
             for p in m.parameters():
@@ -243,7 +249,9 @@ class Trainer(TrainerBase):
             loss_all = loss_all + (self.pro_weight * self.world) * intra_loss                # :465 (x world: see module doc)
             if self.src_reg:
                 loss_all = loss_all + self.src_reg_weight * self.loss_src_reg
+        self._grad_mode((dis, dis2), "input")
         loss_all.backward(inputs=gen_params, retain_graph=True)
+        self._grad_mode((dis, dis2), "auto")
         if self.use_trg_cons and intra_loss is not None and self.retrify_pesudo:             # Appendix B (unpinned)
             # augmented consistency: pseudo labels of the clean target prediction supervise the prediction on
             # a photometrically augmented copy, on the pixels the MC-dropout std marked reliable
@@ -260,7 +268,9 @@ class Trainer(TrainerBase):
         loss_D_same = self._adv(dis2(self._uncertainty(oS)), 1) + self._adv(dis(torch.sigmoid(boundaryS)), 1)
         loss_D_same.backward()
         loss_D_diff = self._adv(D_out1, 0) + self._adv(D_out2, 0)
+        self._grad_mode((dis, dis2), "weights")
         loss_D_diff.backward(inputs=dis_params)
+        self._grad_mode((dis, dis2), "auto")
         del D_out1, D_out2, loss_all
         if self._reducers is not None:
             self._reducers[1].all_reduce_mean()

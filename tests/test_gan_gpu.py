@@ -17,23 +17,32 @@ def _rel(a, b):
 @pytest.mark.parametrize("kind,B,size", [("BoundaryDiscriminator", 2, 128), ("UncertaintyDiscriminator", 2, 128),
                                          ("UncertaintyDiscriminator", 3, 512)])
 def test_discriminator_matches_plain_torch(kind, B, size):
+    """fp64 plain torch = truth.  A LeakyReLU whose pre-activation sits within rounding of 0 legitimately takes the
+    other slope in another fp32 evaluation order (each flip moves one element by 0.8 x its gradient), so gradients
+    are held to a multiple of the distance the fp32 plain-torch run itself has from the fp64 one (trimmed L2)."""
+    import model_cases
     torch.manual_seed(5)
     mine = getattr(GAN, kind)()
     torch.manual_seed(5)
-    ref = getattr(gan_ref, kind)().double()
+    r64 = getattr(gan_ref, kind)().double()
+    torch.manual_seed(5)
+    r32 = getattr(gan_ref, kind)()
     mine.to(DEV)
-    cin = ref.conv1.weight.shape[1]
+    cin = r64.conv1.weight.shape[1]
     x = torch.rand(B, cin, size, size, generator=torch.Generator().manual_seed(1))
-    xa, xb = x.to(DEV).requires_grad_(True), x.double().requires_grad_(True)
-    ya, yb = mine(xa), ref(xb)
+    g = torch.randn((B, 1) + tuple(r32(x[:1]).shape[2:]), generator=torch.Generator().manual_seed(2))
+    xa, xb, xc = x.to(DEV).requires_grad_(True), x.double().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb, yc = mine(xa), r64(xb), r32(xc)
     assert ya.shape == yb.shape
     assert _rel(ya, yb) < 1e-4
-    g = torch.randn(yb.shape, generator=torch.Generator().manual_seed(2))
     ya.backward(g.to(DEV))
     yb.backward(g.double())
-    assert _rel(xa.grad, xb.grad) < 1e-3
-    for i in range(1, 6):
-        assert _rel(getattr(mine, "conv%d" % i).weight.grad, getattr(ref, "conv%d" % i).weight.grad) < 1e-3, i
+    yc.backward(g)
+    pairs = [(xa.grad, xb.grad, xc.grad)] + [(getattr(mine, "conv%d" % i).weight.grad, getattr(r64, "conv%d" % i).weight.grad,
+                                                getattr(r32, "conv%d" % i).weight.grad) for i in range(1, 6)]
+    for i, (a, t, f) in enumerate(pairs):
+        e, floor = model_cases.l2rel(a, t), model_cases.l2rel(f, t)
+        assert e < 10.0 * floor + 1e-4, (i, e, floor)
 
 
 def test_no_grad_forward_and_detached_input():
@@ -41,7 +50,7 @@ def test_no_grad_forward_and_detached_input():
     x = torch.rand(2, 1, 64, 64, device=DEV)
     with torch.no_grad():
         y = d(x)
-    assert not y.requires_grad and y.shape == (2, 1, 5, 5)
+    assert not y.requires_grad and y.shape == (2, 1, 3, 3)
     y = d(x)                                  # detached input: weight gradients only
     y.mean().backward()
     assert d.conv1.weight.grad is not None and torch.isfinite(d.conv5.weight.grad).all()

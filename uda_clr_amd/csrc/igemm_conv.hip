@@ -579,7 +579,7 @@ static inline int grid_for(int64_t total) {
 }
 
 extern "C" int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out, void* stream) {
-    UDA_REQUIRE(w && out && O > 0 && I > 0 && (k == 1 || k == 3), "uda_relayout_ohwi: bad args");
+    UDA_REQUIRE(w && out && O > 0 && I > 0 && (k >= 1 && k <= 3), "uda_relayout_ohwi: bad args");
     const int Kc = ((I + 3) / 4) * 4;
     hipLaunchKernelGGL(relayout_ohwi_kernel, dim3(grid_for((int64_t)O * k * k * Kc)), dim3(256), 0, (hipStream_t)stream,
                        w, O, I, k * k, Kc, out);
@@ -587,7 +587,7 @@ extern "C" int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out
     return 0;
 }
 extern "C" int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* stream) {
-    UDA_REQUIRE(w && out && O > 0 && I > 0 && (k == 1 || k == 3), "uda_relayout_dgrad: bad args");
+    UDA_REQUIRE(w && out && O > 0 && I > 0 && (k >= 1 && k <= 3), "uda_relayout_dgrad: bad args");
     const int Oc = ((O + 3) / 4) * 4;
     hipLaunchKernelGGL(relayout_dgrad_kernel, dim3(grid_for((int64_t)I * k * k * Oc)), dim3(256), 0, (hipStream_t)stream,
                        w, O, I, k * k, Oc, out);

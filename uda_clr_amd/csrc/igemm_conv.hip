@@ -251,6 +251,42 @@ static int check_src(const uda_src_t& s, const char* who) {
     return 0;
 }
 
+// Cout = 1 on a raw operand (the discriminators' last layer, GAN.py:100: 2048 -> 1 over 4 taps): a dot product
+// per pixel, one wave per pixel, 16-byte loads along the contiguous channels; HBM-bound (reads the operand once),
+// where a 128 x 32 MFMA tile would run 46 workgroups with one useful column.
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvKArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int H = a.src.H, W = a.src.W;
+    const int64_t P = (int64_t)a.src.N * H * W;
+    if (p >= P) return;
+    const int pw = (int)(p % W), ph = (int)((p / W) % H);
+    const int T = a.ksize * a.ksize;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const int th = t / a.ksize;
+        const int hh = ph + (th - a.cen) * a.dil, ww = pw + (t - th * a.ksize - a.cen) * a.dil;
+        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+        const float* xr = a.src.x + (p + (int64_t)(hh - ph) * W + (ww - pw)) * a.src.ldx;
+        const float* wr = a.w + (int64_t)t * a.Kc;
+        for (int c = lane * 4; c < a.Kc; c += 256) {
+            const float4 xv = uda_ld4(xr + c), wv = uda_ld4(wr + c);      // weight rows are zero beyond C
+            float s = xv.x * wv.x;
+            if (c + 1 < a.src.C) s += xv.y * wv.y;
+            if (c + 2 < a.src.C) s += xv.z * wv.z;
+            if (c + 3 < a.src.C) s += xv.w * wv.w;
+            acc += s;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        float v = acc + (a.bias ? a.bias[0] : 0.f);
+        if (a.addend) v += a.addend[p * a.ld_add];
+        a.y[p * a.ldy] = v;
+    }
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -289,6 +325,11 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.stats = a->stats;
     k.debug = 0;
     int e;
+    if (a->Cout == 1 && !a->src.scale && !a->src.mask && a->src.act == ACT_NONE && !a->stats && k.Ktot >= 1024) {
+        hipLaunchKernelGGL(conv_cout1_kernel, dim3(uda_cdiv(P, 4)), dim3(256), 0, st, k);
+        UDA_LAUNCH_CHECK("conv_cout1");
+        return 0;
+    }
     if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);

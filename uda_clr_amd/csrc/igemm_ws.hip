@@ -352,7 +352,7 @@ static int launch_ws_xf(ConvKArgs& k, int64_t P, hipStream_t st) {
 template <int KS>
 static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, bool tall, hipStream_t st) {
     switch (tn) {
-        case 2: return launch_ws_xf<KS, 2, 128>(k, P, st);
+        case 2: return launch_ws_xf<KS, 2, 128>(k, P, st);      // two 128x128 workgroups per CU beat one 256x128 (measured)
         case 3: return launch_ws_xf<KS, 3, 128>(k, P, st);
         case 4: return tall ? launch_ws_xf<KS, 4, 256>(k, P, st) : launch_ws_xf<KS, 4, 128>(k, P, st);
         default: return launch_ws_xf<KS, 5, 128>(k, P, st);

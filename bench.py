@@ -140,8 +140,6 @@ def main():
     ap.add_argument("--backbone", choices=("mobilenet", "resnet"), default="mobilenet",
                     help="resnet = the ResNet-101 variant of BASELINE.json configs[4] (quoted at --batch 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dis-channels-last", action="store_true", help="run the stock-torch discriminators in channels_last")
-    ap.add_argument("--miopen-benchmark", action="store_true", help="let MIOpen search conv algorithms for the stock-torch discriminators")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,7 +149,6 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -188,8 +185,6 @@ def main():
         per_step = args.batch
     else:
         d1, d2 = BoundaryDiscriminator().to(dev).train(), UncertaintyDiscriminator().to(dev).train()
-        if args.dis_channels_last:
-            d1, d2 = d1.to(memory_format=torch.channels_last), d2.to(memory_format=torch.channels_last)
         od = torch.optim.SGD(d1.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=5e-4)
         od2 = torch.optim.SGD(d2.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=5e-4)
         tr = Trainer_prototype_full.Trainer(

@@ -497,7 +497,9 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     };
 
     const int wm = (wave & 3) >> 1, wn = wave & 1;
-    const int acol = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), kh = lane >> 5;
+    // MFMA row/column slot r of a wave owns tile rows 2r and 2r+1 (blocks i = 0, 1): the two values a lane needs per
+    // k-step are adjacent in LDS and come with ONE ds_read_b64 per operand (was two ds_read_b32)
+    const int acol = wm * 64 + 2 * (lane & 31), bcol = wn * 64 + 2 * (lane & 31), kh = lane >> 5;
     const int n = c1 - c0;
     if (loader) {
         if (n > 0) {
@@ -527,11 +529,10 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
             const float* Bs = As + WG_BKP * BM;
 #pragma unroll
             for (int kk = 0; kk < WG_BKP / 2; ++kk) {
-                float af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + kh) * BM + acol + 32 * i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kk + kh) * BN + bcol + 32 * j];
+                static_assert(TM == 2 && TN == 2, "paired-row fragment reads");
+                const float2 a2 = *reinterpret_cast<const float2*>(&As[(2 * kk + kh) * BM + acol]);
+                const float2 b2 = *reinterpret_cast<const float2*>(&Bs[(2 * kk + kh) * BN + bcol]);
+                const float af[TM] = {a2.x, a2.y}, bf[TN] = {b2.x, b2.y};
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -545,10 +546,10 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = jt * BN + wn * 64 + 32 * j + (lane & 31);
+                const int col = jt * BN + wn * 64 + 2 * (lane & 31) + j;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = cot * BM + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int row = cot * BM + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + i;
                     if (row < a.Cout && col < a.Jtot) slab[(int64_t)row * a.Jtot + col] = acc[i][j][r];
                 }
             }

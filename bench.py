@@ -57,12 +57,12 @@ class ConvTimer:
         self.events, self.flops, self.bytes, self.enabled = [], [], [], False
         kernels.conv = self._conv
 
-    def _conv(self, src, w, ksize, dil, out, bias=None, addend=None, stats=None):
+    def _conv(self, src, w, ksize, dil, out, bias=None, addend=None, stats=None, **kw):
         hot = self.enabled and ksize == 3 and out.shape[1] > 96
         if hot:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.orig(src, w, ksize, dil, out, bias, addend, stats)
+        self.orig(src, w, ksize, dil, out, bias, addend, stats, **kw)
         if hot:
             e1.record()
             self.events.append((e0, e1))

@@ -48,9 +48,10 @@ def synth_batch(B, S, seed, device):
 
 
 class ConvTimer:
-    """HIP-event timing of the dominant kernel's launches inside the timed region: wraps
-    HipKernels.conv and records an event pair around every 3x3 implicit-GEMM launch (forward and
-    input-gradient of the decoder / ASPP 3x3 convolutions - one kernel symbol)."""
+    """HIP-event timing of the dominant kernel's launches inside the timed region: wraps HipKernels.conv and
+    records an event pair around every launch of the wide-tile multi-tap implicit GEMM (one kernel symbol,
+    igemm_conv_ws_kernel<3,...>: forward and input-gradient of the decoder / ASPP 3x3 convolutions and of the
+    discriminators' 4x4 stride-2 convolutions in their 2x2 space-to-depth form)."""
 
     def __init__(self, kernels):
         self.k, self.orig = kernels, kernels.conv
@@ -58,7 +59,7 @@ class ConvTimer:
         kernels.conv = self._conv
 
     def _conv(self, src, w, ksize, dil, out, bias=None, addend=None, stats=None, **kw):
-        hot = self.enabled and ksize == 3 and out.shape[1] > 96
+        hot = self.enabled and ksize >= 2 and out.shape[1] > 96 and ksize * ksize * src.C > 192      # the wide-tile multi-tap kernel
         if hot:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -66,8 +67,9 @@ class ConvTimer:
         if hot:
             e1.record()
             self.events.append((e0, e1))
-            self.flops.append(2.0 * src.P * out.shape[1] * 9 * src.C)      # algorithmic: 2*P*Cout*9*Cin
-            self.bytes.append(4.0 * (src.P * (src.C + out.shape[1]) + out.shape[1] * 9 * src.C))   # in + out + weights, once each
+            taps = ksize * ksize
+            self.flops.append(2.0 * src.P * out.shape[1] * taps * src.C)      # algorithmic: 2*P*Cout*taps*Cin
+            self.bytes.append(4.0 * (src.P * (src.C + out.shape[1]) + out.shape[1] * taps * src.C))   # in + out + weights, once each
 
     def summary(self, traffic=None):
         """traffic: measured HBM bytes per launch (rocprofv3 PMC passes, profiles/*_traffic.json) or None."""
@@ -78,7 +80,8 @@ class ConvTimer:
         return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_gb_per_launch": round(sum(self.bytes) / len(ms) / 1e9, 4),
-                "kernel": "igemm_conv_ws_kernel<3,*,*> (3x3 implicit GEMM: forward + input-gradient of the decoder and ASPP convs)",
+                "kernel": "igemm_conv_ws_kernel<3,*> (multi-tap implicit GEMM: forward + input-gradient of the decoder / ASPP 3x3 "
+                          "convs and of the discriminators' 4x4 s2 convs as 2x2 space-to-depth convs)",
                 "launches": len(ms), "avg_launch_ms": round(sum(ms) / len(ms), 4),
                 "algorithmic_gflop_per_launch": round(sum(self.flops) / len(ms) / 1e9, 2)}
 

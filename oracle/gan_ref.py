@@ -1,9 +1,9 @@
 """Plain-PyTorch restatement of the reference's patch discriminators (networks/GAN.py:86-148).
 
 TEST INFRASTRUCTURE (see oracle/__init__.py): five Conv2d(4, stride 2, pad 2, bias=False) with LeakyReLU(0.2)
-between them, weights ~ N(0, 0.02) drawn in construction order.  Pinned: tests/golden/make_golden.py runs the
-reference's own Trainer_prototype_full loop with the reference's discriminators and this file's copies side by
-side (trainer_proto.json), and tests/golden/gan.npz holds outputs / gradient norms of the reference's modules.
+between them, weights ~ N(0, 0.02) drawn in construction order.  Pinned through tests/golden/trainer_proto.json:
+the rows (seg, adv, D_same, D_diff, intra, inter) the reference's own Trainer_prototype_full loop wrote with the
+reference's own discriminators (seeded 1338) are reproduced by tests/test_trainers_cpu.py with these copies.
 """
 import torch.nn as nn
 import torch.nn.functional as F

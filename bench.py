@@ -53,17 +53,22 @@ class ConvTimer:
     igemm_conv_ws_kernel<3,...>: forward and input-gradient of the decoder / ASPP 3x3 convolutions and of the
     discriminators' 4x4 stride-2 convolutions in their 2x2 space-to-depth form)."""
 
-    def __init__(self, kernels):
-        self.k, self.orig = kernels, kernels.conv
+    def __init__(self, kernel_class):
+        """Patches the binding CLASS so that every HipKernels instance (generator engine, discriminator engines) is timed."""
+        self.orig = kernel_class.conv
         self.events, self.flops, self.bytes, self.enabled = [], [], [], False
-        kernels.conv = self._conv
+        timer = self
 
-    def _conv(self, src, w, ksize, dil, out, bias=None, addend=None, stats=None, **kw):
+        def conv(inst, *a, **kw):
+            return timer._conv(inst, *a, **kw)
+        kernel_class.conv = conv
+
+    def _conv(self, inst, src, w, ksize, dil, out, bias=None, addend=None, stats=None, **kw):
         hot = self.enabled and ksize >= 2 and out.shape[1] > 96 and ksize * ksize * src.C > 192      # the wide-tile multi-tap kernel
         if hot:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.orig(src, w, ksize, dil, out, bias, addend, stats, **kw)
+        self.orig(inst, src, w, ksize, dil, out, bias, addend, stats, **kw)
         if hot:
             e1.record()
             self.events.append((e0, e1))
@@ -203,7 +208,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = ConvTimer(model._engine_for(img).K)
+    from uda_clr_amd.kernels import HipKernels
+    timer = ConvTimer(HipKernels)
 
     def sync():
         if dist is not None:

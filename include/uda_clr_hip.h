@@ -52,9 +52,12 @@ const char* uda_last_error(void);
 int uda_version(void);
 
 /* ---- weight re-layouts (tiny; once per step).  torch layout OIHW in. */
-/* out[O][k*k][round4(I)] (zero padded)              - operand of uda_conv_fwd              */
+/* K order of one weight row: k = 1: [round4(I)];  k > 1 ("tap-chunked"): [nCC][k*k][32] with nCC = ceil(round4(I)/32),
+ * i.e. element (tap t, channel c) at ((c/32)*k*k + t)*32 + c%32, zero padded: all taps of one 32-channel slice are
+ * consecutive K-chunks of the implicit GEMM, so a workgroup re-reads its pixel strip while it is L2-resident.
+ * out[O][row as above]                              - operand of uda_conv_fwd              */
 int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out, void* stream);
-/* out[I][k*k][round4(O)], taps flipped             - operand of uda_conv_fwd used as dgrad */
+/* out[I][row over O as above], taps flipped        - operand of uda_conv_fwd used as dgrad */
 int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* stream);
 /* depthwise [C][1][3][3] -> [9][C] */
 int uda_relayout_dw(const float* w, int C, float* out, void* stream);
@@ -67,7 +70,7 @@ int uda_relayout_dw(const float* w, int C, float* out, void* stream);
  * before addend. */
 typedef struct uda_conv_args {
     uda_src_t src;
-    const float* w;        /* [Cout][ksize*ksize][round4(src.C)] */
+    const float* w;        /* [Cout][row], the layout uda_relayout_ohwi writes */
     int32_t Cout, ksize, dil;
     int32_t origin;        /* ksize 2 only: tap (kh,kw) reads pixel (h + kh - origin, w + kw - origin); 0 = the
                               space-to-depth form of the 4x4 stride-2 convs of GAN.py:90-101, 1 = its input gradient.

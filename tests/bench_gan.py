@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from uda_clr_amd.acts import Act, round4
+from uda_clr_amd.acts import Act, conv_weight_shape, round4
 from uda_clr_amd.kernels import HipKernels
 
 dev = torch.device("cuda:0")
@@ -35,8 +35,8 @@ for l in range(5):
     P = B * Hz * Hz
     z = torch.randn(P, 4 * Cc, device=dev)
     dy = torch.randn(P, round4(O), device=dev)[:, :O]
-    w = torch.randn(O, 4, 4 * Cc, device=dev)
-    wd = torch.randn(4 * Cc, 4, round4(O), device=dev)
+    w = torch.randn(conv_weight_shape(O, 2, 4 * Cc), device=dev)
+    wd = torch.randn(conv_weight_shape(4 * Cc, 2, O), device=dev)
     y = torch.empty(P, round4(O), device=dev)[:, :O]
     dz = torch.empty(P, 4 * Cc, device=dev)
     dw = torch.empty(O, 4 * Cc, 2, 2, device=dev)

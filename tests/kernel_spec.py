@@ -13,7 +13,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from uda_clr_amd.acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, round4
+from uda_clr_amd.acts import ACT_NONE, ACT_RELU, ACT_RELU6, K_CHUNK, Act, round4, tap_chunked
 
 
 def _apply_act(a, act):
@@ -75,16 +75,33 @@ class SpecKernels:
 
     # ------------------------------------------------------------------ weight layouts
     def relayout_ohwi(self, w):
+        """[O, I, kh, kw] -> [O, 1, round4(I)] for 1x1, else the tap-chunked K order [O, nCC*T, 32] (acts.tap_chunked)."""
         O, I, kh, kw = w.shape
-        out = w.new_zeros(O, kh * kw, round4(I))
-        out[:, :, :I] = w.permute(0, 2, 3, 1).reshape(O, kh * kw, I)
+        rtc = w.permute(0, 2, 3, 1).reshape(O, kh * kw, I)
+        if kh * kw > 1:
+            return tap_chunked(rtc)
+        out = w.new_zeros(O, 1, round4(I))
+        out[:, :, :I] = rtc
         return out
 
     def relayout_dgrad(self, w):
+        """rows = input channels, taps flipped, channels = output channels (operand of conv used as dgrad)."""
         O, I, kh, kw = w.shape
-        out = w.new_zeros(I, kh * kw, round4(O))
-        out[:, :, :O] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(I, kh * kw, O)
+        rtc = w.flip(2, 3).permute(1, 2, 3, 0).reshape(I, kh * kw, O)
+        if kh * kw > 1:
+            return tap_chunked(rtc)
+        out = w.new_zeros(I, 1, round4(O))
+        out[:, :, :O] = rtc
         return out
+
+    @staticmethod
+    def _taps_channels(w, T, Cin):
+        """inverse of the weight layout: [R, T, Cin]"""
+        R = w.shape[0]
+        if T == 1:
+            return w[:, :, :Cin]
+        ncc = w.shape[1] // T
+        return w.reshape(R, ncc, T, K_CHUNK).permute(0, 2, 1, 3).reshape(R, T, ncc * K_CHUNK)[:, :, :Cin]
 
     def relayout_dw(self, w):
         return w.reshape(w.shape[0], 9).t().contiguous()
@@ -102,11 +119,11 @@ class SpecKernels:
 
     def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
         """out[p, co] = bias[co] + addend[p, co] + sum_{t, ci} u(p + off_t, ci) * w[co, t, ci];
-        ``w`` is [Cout, ksize^2, round4(Cin)]; stats (fp64 [2, Cout]) receives sum and sum of squares of the
+        ``w`` is the relayout_ohwi operand; stats (fp64 [2, Cout]) receives sum and sum of squares of the
         value before ``addend``."""
         Cin, Cout = src.C, out.shape[1]
         u = self._pad_taps(_nchw(transform(src), src.N, src.H, src.W), ksize, dil, origin)
-        w4 = w[:, :, :Cin].reshape(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
+        w4 = self._taps_channels(w, ksize * ksize, Cin).reshape(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
         y = _rows(F.conv2d(u, w4, bias, 1, 0, dil if ksize == 3 else 1))
         if stats is not None:
             stats[0, 0] += y.double().sum(0)

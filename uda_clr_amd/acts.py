@@ -78,3 +78,24 @@ def nchw_view(x2d: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
     """Logical [N, C, H, W] view (channels-last strides) of a [P, C] NHWC matrix."""
     ld, C = x2d.stride(0), x2d.shape[1]
     return x2d.as_strided((N, C, H, W), (H * W * ld, 1, W * ld, ld), x2d.storage_offset())
+
+
+K_CHUNK = 32      # IG_BK of the implicit-GEMM kernels
+
+
+def tap_chunked(w_rtc: torch.Tensor) -> torch.Tensor:
+    """[R, T, C] (rows, taps, channels) -> the K order of the multi-tap implicit-GEMM kernels, [R, nCC*T, 32]:
+    k = (cc*T + t)*32 + c % 32 with cc = c // 32, channels zero-padded to a multiple of 32.  All T taps of one
+    32-channel slice are consecutive K-chunks, so a workgroup re-reads its pixel strip while it is L2-resident."""
+    R, T, Cc = w_rtc.shape
+    ncc = (Cc + K_CHUNK - 1) // K_CHUNK
+    out = w_rtc.new_zeros(R, T, ncc * K_CHUNK)
+    out[:, :, :Cc] = w_rtc
+    return out.reshape(R, T, ncc, K_CHUNK).permute(0, 2, 1, 3).reshape(R, ncc * T, K_CHUNK).contiguous()
+
+
+def conv_weight_shape(rows: int, ksize: int, channels: int):
+    """Shape of the relayouted weight operand of ``conv``: [rows, 1, round4(C)] for 1x1, tap-chunked otherwise."""
+    if ksize == 1:
+        return (rows, 1, round4(channels))
+    return (rows, ((channels + K_CHUNK - 1) // K_CHUNK) * ksize * ksize, K_CHUNK)

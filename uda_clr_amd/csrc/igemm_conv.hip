@@ -1,7 +1,10 @@
 // FP32-MFMA implicit-GEMM convolution for gfx950 (stride 1, 1x1 / 3x3, any dilation), NHWC.
 //
-//   y[p, co] = bias[co] + addend[p, co] + sum_k A(p, k) * Wt[co, k],      k = t*Kc + ci
+//   y[p, co] = bias[co] + addend[p, co] + sum_k A(p, k) * Wt[co, k]
 //   A(p, k)  = u(p + off_t, ci)  (prologue-transformed input, 0 outside the image / ci >= C)
+//   K order ("tap-chunked"): chunk = cc*T + t covers channels 32cc .. 32cc+31 of tap t, so all T taps of one
+//   channel slice are consecutive chunks and re-read the workgroup's pixel strip while it is L2-resident
+//   (PMC: 1.6x the algorithmic bytes on the memory side; the tap-major order k = t*Kc + ci measured 4.6x).
 //
 // Roofline: MFMA-bound for the decoder / ASPP 3x3 convs (560 / 284 FLOP per byte) on
 // v_mfma_f32_32x32x2_f32 (exact fp32, 157.3 TF peak, 64 cycles per instruction per SIMD); the
@@ -61,13 +64,14 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     bool c_kval = false;
 
     auto issue = [&](int chunk) {
-        const int k0 = chunk * IG_BK + kv;
-        c_kval = k0 < a.Ktot;
+        const int k0 = chunk * IG_BK + kv;          // position in the weight row
         int t = 0, ci = k0;
-        if (a.ksize >= 2) {
-            t = k0 / a.Kc;
-            ci = k0 - t * a.Kc;
+        if (a.ksize >= 2) {                          // tap-chunked K: chunk = cc * T + t
+            const int T = a.ksize * a.ksize;
+            t = chunk % T;
+            ci = (chunk / T) * IG_BK + kv;
         }
+        c_kval = k0 < a.Ktot && ci < a.Kc;
         c_ci = ci;
         int dh = 0, dw = 0;
         if (a.ksize >= 2) {
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + lrow + 32 * i;
-            breg[i] = (c_kval && n < a.Cout) ? uda_ld4(a.w + (int64_t)n * a.Ktot + k0)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            breg[i] = (k0 < a.Ktot && n < a.Cout) ? uda_ld4(a.w + (int64_t)n * a.Ktot + k0)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -240,6 +244,12 @@ int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hi
     return 0;
 }
 
+// floats per weight row of a conv with C input channels and ksize x ksize taps
+static inline int uda_k_row(int C, int ksize) {
+    const int Kc = ((C + 3) / 4) * 4;
+    return ksize == 1 ? Kc : ((Kc + IG_BK - 1) / IG_BK) * ksize * ksize * IG_BK;
+}
+
 static int check_src(const uda_src_t& s, const char* who) {
     UDA_REQUIRE(s.x && uda_aligned16(s.x), "%s: src.x must be 16-byte aligned", who);
     UDA_REQUIRE(s.ldx % 4 == 0 && s.ldx >= ((s.C + 3) / 4) * 4, "%s: src.ldx=%lld must be a multiple of 4 and >= round4(C=%d)",
@@ -268,9 +278,10 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvKArgs a) {
         const int hh = ph + (th - a.cen) * a.dil, ww = pw + (t - th * a.ksize - a.cen) * a.dil;
         if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
         const float* xr = a.src.x + (p + (int64_t)(hh - ph) * W + (ww - pw)) * a.src.ldx;
-        const float* wr = a.w + (int64_t)t * a.Kc;
         for (int c = lane * 4; c < a.Kc; c += 256) {
-            const float4 xv = uda_ld4(xr + c), wv = uda_ld4(wr + c);      // weight rows are zero beyond C
+            // tap-chunked weight row (T > 1): k = ((c / 32) * T + t) * 32 + c % 32; zero beyond C
+            const int kq = T == 1 ? c : ((c / IG_BK) * T + t) * IG_BK + (c % IG_BK);
+            const float4 xv = uda_ld4(xr + c), wv = uda_ld4(a.w + kq);
             float s = xv.x * wv.x;
             if (c + 1 < a.src.C) s += xv.y * wv.y;
             if (c + 2 < a.src.C) s += xv.z * wv.z;
@@ -316,7 +327,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.dil = a->dil;
     k.cen = a->ksize == 3 ? 1 : (a->ksize == 2 ? a->origin : 0);
     k.Kc = ((a->src.C + 3) / 4) * 4;
-    k.Ktot = a->ksize * a->ksize * k.Kc;
+    k.Ktot = uda_k_row(a->src.C, a->ksize);
     k.bias = a->bias;
     k.addend = a->addend;
     k.ld_add = a->ld_add;
@@ -595,17 +606,36 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
 
 // ==========================================================================================
 // weight re-layouts
-__global__ void relayout_ohwi_kernel(const float* __restrict__ w, int O, int I, int T, int Kc, float* __restrict__ out) {
-    const int64_t total = (int64_t)O * T * Kc;
+// K order of a weight row: T == 1: [Kc];  T > 1 ("tap-chunked"): [nCC][T][32], k = (cc*T + t)*32 + c % 32 with
+// cc = c / 32, channels zero-padded to a multiple of 32: all T taps of one 32-channel slice are consecutive
+// K-chunks, so a workgroup re-reads its pixel strip while it is still L2-resident (the tap-major order re-read it from
+// the memory side: 5x the algorithmic bytes on FETCH_SIZE).
+__device__ __forceinline__ void uda_k_decode(int64_t e, int T, int Kr, int& c, int& t, int& row) {
+    // e indexes [row][Kr]; Kr = Kc (T == 1) or nCC*T*32
+    const int k = (int)(e % Kr);
+    row = (int)(e / Kr);
+    if (T == 1) {
+        c = k;
+        t = 0;
+    } else {
+        const int chunk = k / IG_BK;
+        t = chunk % T;
+        c = (chunk / T) * IG_BK + (k % IG_BK);
+    }
+}
+__global__ void relayout_ohwi_kernel(const float* __restrict__ w, int O, int I, int T, int Kr, float* __restrict__ out) {
+    const int64_t total = (int64_t)O * Kr;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(e % Kc), t = (int)((e / Kc) % T), o = (int)(e / ((int64_t)Kc * T));
+        int ci, t, o;
+        uda_k_decode(e, T, Kr, ci, t, o);
         out[e] = ci < I ? w[((int64_t)o * I + ci) * T + t] : 0.f;
     }
 }
-__global__ void relayout_dgrad_kernel(const float* __restrict__ w, int O, int I, int T, int Oc, float* __restrict__ out) {
-    const int64_t total = (int64_t)I * T * Oc;
+__global__ void relayout_dgrad_kernel(const float* __restrict__ w, int O, int I, int T, int Kr, float* __restrict__ out) {
+    const int64_t total = (int64_t)I * Kr;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int o = (int)(e % Oc), t = (int)((e / Oc) % T), ci = (int)(e / ((int64_t)Oc * T));
+        int o, t, ci;
+        uda_k_decode(e, T, Kr, o, t, ci);
         out[e] = o < O ? w[((int64_t)o * I + ci) * T + (T - 1 - t)] : 0.f;
     }
 }
@@ -621,17 +651,17 @@ static inline int grid_for(int64_t total) {
 
 extern "C" int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out, void* stream) {
     UDA_REQUIRE(w && out && O > 0 && I > 0 && (k >= 1 && k <= 3), "uda_relayout_ohwi: bad args");
-    const int Kc = ((I + 3) / 4) * 4;
-    hipLaunchKernelGGL(relayout_ohwi_kernel, dim3(grid_for((int64_t)O * k * k * Kc)), dim3(256), 0, (hipStream_t)stream,
-                       w, O, I, k * k, Kc, out);
+    const int Kr = uda_k_row(I, k);
+    hipLaunchKernelGGL(relayout_ohwi_kernel, dim3(grid_for((int64_t)O * Kr)), dim3(256), 0, (hipStream_t)stream,
+                       w, O, I, k * k, Kr, out);
     UDA_LAUNCH_CHECK("relayout_ohwi");
     return 0;
 }
 extern "C" int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* stream) {
     UDA_REQUIRE(w && out && O > 0 && I > 0 && (k >= 1 && k <= 3), "uda_relayout_dgrad: bad args");
-    const int Oc = ((O + 3) / 4) * 4;
-    hipLaunchKernelGGL(relayout_dgrad_kernel, dim3(grid_for((int64_t)I * k * k * Oc)), dim3(256), 0, (hipStream_t)stream,
-                       w, O, I, k * k, Oc, out);
+    const int Kr = uda_k_row(O, k);
+    hipLaunchKernelGGL(relayout_dgrad_kernel, dim3(grid_for((int64_t)I * Kr)), dim3(256), 0, (hipStream_t)stream,
+                       w, O, I, k * k, Kr, out);
     UDA_LAUNCH_CHECK("relayout_dgrad");
     return 0;
 }

@@ -65,7 +65,8 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
     unsigned aok = 0;
     Xf4 xf;
     int st_ci = 0;               // channel of the staged registers' first element
-    int t_cur = 0, ci_cur = kv;  // (tap, channel) of the NEXT chunk to issue
+    int t_cur = 0, ci_cur = kv;  // (tap, channel) of the NEXT chunk to issue: tap-chunked K, chunk = cc * T + t
+    int kb_cur = kv;             // its position in the weight row
     if (loader) {
         const int ldx = (int)a.src.ldx, ldm = (int)a.src.ldm;
 #pragma unroll
@@ -96,15 +97,11 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
             const int n = n0 + lrow + 32 * i;
             boff[i] = n < a.Cout ? n * a.Ktot : -1;
         }
-        if (KS == 3) {
-            t_cur = kv / a.Kc;
-            ci_cur = kv - t_cur * a.Kc;
-        }
     }
 
     auto issue = [&]() {       // loads of the chunk at (t_cur, ci_cur); then advance by BK
         const int t = t_cur, ci = ci_cur;
-        const bool kval = KS == 3 ? (t < a.ksize * a.ksize) : (ci < a.Kc);
+        const bool kval = ci < a.Kc;
         st_ci = ci;
         int tapoff = 0;
         if (KS == 3) {
@@ -127,16 +124,18 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
                 aok |= 1u << i;
             }
         }
-        const int k0 = KS == 3 ? t * a.Kc + ci : ci;
+        const int k0 = kb_cur;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            breg[i] = (kval && boff[i] >= 0) ? uda_ld4(a.w + (boff[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ci_cur += IG_BK;
+            breg[i] = (k0 < a.Ktot && boff[i] >= 0) ? uda_ld4(a.w + (boff[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kb_cur += IG_BK;
         if (KS == 3) {
-            while (ci_cur >= a.Kc) {
-                ci_cur -= a.Kc;
-                ++t_cur;
+            if (++t_cur == a.ksize * a.ksize) {
+                t_cur = 0;
+                ci_cur += IG_BK;
             }
+        } else {
+            ci_cur += IG_BK;
         }
     };
 

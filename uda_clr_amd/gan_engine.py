@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from .acts import Act, round4
+from .acts import Act, round4, tap_chunked
 
 SLOPE = 0.2
 
@@ -35,9 +35,8 @@ class PatchDiscriminatorEngine:
             return hit[1], hit[2]
         O, Cc = w.shape[0], w.shape[1]
         wz = w.detach().reshape(O, Cc, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(O, 4, 4 * Cc)   # o, (u,v), (a,b,c)
-        fwd = wz.contiguous()
-        dg = torch.zeros(4 * Cc, 4, round4(O), dtype=w.dtype, device=w.device)
-        dg[:, :, :O] = wz.flip(1).permute(2, 1, 0)                                                   # (a,b,c), flipped tap, o
+        fwd = tap_chunked(wz)                                                                        # K order of the kernels
+        dg = tap_chunked(wz.flip(1).permute(2, 1, 0))                                                # (a,b,c), flipped tap, o
         self._wcache[id(w)] = (key, fwd, dg)
         return fwd, dg
 

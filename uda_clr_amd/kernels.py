@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-from .acts import Act, round4
+from .acts import conv_weight_shape, Act, round4
 
 STAT_SLOTS = 16      # UDA_STAT_SLOTS in include/uda_clr_hip.h
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libuda_clr_hip.so")
@@ -175,13 +175,13 @@ class HipKernels:
     # ------------------------------------------------------------------ weight layouts
     def relayout_ohwi(self, w):
         O, I, k, _ = w.shape
-        out = torch.empty(O, k * k, round4(I), dtype=torch.float32, device=w.device)
+        out = torch.empty(conv_weight_shape(O, k, I), dtype=torch.float32, device=w.device)
         self._ck(self.lib.uda_relayout_ohwi(w.contiguous().data_ptr(), O, I, k, out.data_ptr(), self._stream()))
         return out
 
     def relayout_dgrad(self, w):
         O, I, k, _ = w.shape
-        out = torch.empty(I, k * k, round4(O), dtype=torch.float32, device=w.device)
+        out = torch.empty(conv_weight_shape(I, k, O), dtype=torch.float32, device=w.device)
         self._ck(self.lib.uda_relayout_dgrad(w.contiguous().data_ptr(), O, I, k, out.data_ptr(), self._stream()))
         return out
 
@@ -197,7 +197,7 @@ class HipKernels:
         a.origin = origin
         a.src = self._src(src)
         Cout = out.shape[1]
-        assert w.is_contiguous() and tuple(w.shape) == (Cout, ksize * ksize, round4(src.C)), \
+        assert w.is_contiguous() and tuple(w.shape) == conv_weight_shape(Cout, ksize, src.C), \
             "weight layout %s does not match conv %dx%d %d->%d" % (tuple(w.shape), ksize, ksize, src.C, Cout)
         assert out.shape[0] == src.P
         a.w, a.Cout, a.ksize, a.dil = w.data_ptr(), Cout, ksize, dil

@@ -86,6 +86,16 @@ wgrad_case("wgrad1x1 1280->256 32^2 lazy", B, 32, 32, 1280, 256, 1, 1, True)
 
 
 def ew_cases():
+    for (Cc, H) in ((96, 256), (144, 128), (24, 128), (384, 32)):      # backbone shapes: no mask, relu6
+        P = B * H * H
+        y = src(B, H, H, Cc, True, False)
+        y.act = ACT_RELU6
+        y.bn = BNRec("t", torch.randn(Cc, device=dev), torch.rand(Cc, device=dev) + 0.5, float(P))
+        dU = torch.randn(P, round4(Cc), device=dev)[:, :Cc]
+        c = torch.randn(4, Cc, device=dev)
+        sums = torch.zeros(16, 3, Cc, dtype=torch.float64, device=dev)
+        report("bnbwd_reduce %dch %d^2" % (Cc, H), timeit(lambda: K.bnbwd_reduce(dU, y, sums)), 0, P * Cc * 8.0)
+        report("bnbwd_apply %dch %d^2" % (Cc, H), timeit(lambda: K.bnbwd_apply(dU, y, c[0], c[1], dU)), 0, P * Cc * 12.0)
     P, C = B * 128 * 128, 256
     y = src(B, 128, 128, C, True, True)
     y.bn = BNRec("t", torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5, float(P))

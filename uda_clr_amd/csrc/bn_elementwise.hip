@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
         }
     }
     const int64_t base = (int64_t)blockIdx.x * (PP * RED_ITER);
+#pragma unroll 4
     for (int it = 0; it < RED_ITER; ++it) {
         const int64_t p = base + (int64_t)it * PP + pl;
         if (!active || p >= a.P) continue;

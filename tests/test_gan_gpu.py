@@ -54,3 +54,24 @@ def test_no_grad_forward_and_detached_input():
     y = d(x)                                  # detached input: weight gradients only
     y.mean().backward()
     assert d.conv1.weight.grad is not None and torch.isfinite(d.conv5.weight.grad).all()
+
+
+def test_forward_follows_fused_optimizer_steps():
+    """torch's fused multi-tensor optimizers update parameters without bumping their autograd version: the kernel-side
+    weight layouts must not be cached on it (regression: a discriminator frozen at its initial weights)."""
+    torch.manual_seed(7)
+    d = GAN.BoundaryDiscriminator().to(DEV)
+    torch.manual_seed(7)
+    ref = gan_ref.BoundaryDiscriminator()
+    opt = torch.optim.SGD(d.parameters(), lr=0.5, momentum=0.9, fused=True)
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=0.5, momentum=0.9)
+    x = torch.rand(2, 1, 64, 64, generator=torch.Generator().manual_seed(3))
+    for _ in range(3):
+        for o, m, xx in ((opt, d, x.to(DEV)), (opt_ref, ref, x)):
+            o.zero_grad()
+            m(xx).square().mean().backward()
+            o.step()
+    with torch.no_grad():
+        ya, yb = d(x.to(DEV)), ref(x)
+    assert (yb - gan_ref.BoundaryDiscriminator()(x)).abs().max() > 0        # the weights really moved
+    assert _rel(ya, yb) < 1e-3

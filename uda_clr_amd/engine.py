@@ -123,7 +123,6 @@ class GeneratorEngine:
         self.dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
         self.seed = seed
         self.rng_offset = 0
-        self._wcache = {}
         # channels that receive BN statistics in one forward (stem, blocks, ASPP, decoder)
         if backbone == "mobilenet":
             self.blocks = block_plan(output_stride)
@@ -154,18 +153,14 @@ class GeneratorEngine:
         return ctx.arena.take(2, C) if training else None
 
     def _w(self, ctx, key, kind):
-        """Kernel-side layout of a weight, cached until the parameter is written again (optimizer step, load_state_dict):
-        the source / target / stochastic passes of one iteration share the relayouts."""
+        """Kernel-side layout of a weight, built once per forward context.  (Not cached across forwards: the fused
+        multi-tensor optimizer steps of torch do not bump a parameter's autograd version, so staleness could not be
+        detected.)"""
         ck = (key, kind)
         if ck not in ctx.w_cache:
             w = ctx.params[key]
-            tag = (w.data_ptr(), w._version, tuple(w.shape))
-            hit = self._wcache.get(ck)
-            if hit is None or hit[0] != tag:
-                hit = (tag, {"ohwi": self.K.relayout_ohwi, "dgrad": self.K.relayout_dgrad,
-                             "dw": self.K.relayout_dw}[kind](w))
-                self._wcache[ck] = hit
-            ctx.w_cache[ck] = hit[1]
+            ctx.w_cache[ck] = {"ohwi": self.K.relayout_ohwi, "dgrad": self.K.relayout_dgrad,
+                               "dw": self.K.relayout_dw}[kind](w)
         return ctx.w_cache[ck]
 
     def _bn(self, ctx, prefix, stats, count, training, scale, shift, mean=None, invstd=None,

@@ -25,20 +25,14 @@ def _zgrid(v):
 class PatchDiscriminatorEngine:
     def __init__(self, kernels):
         self.K = kernels
-        self._wcache = {}
 
-    # z-space weight layouts of a [O, C, 4, 4] tensor, cached until the parameter changes
-    def _weights(self, w):
-        key = (w.data_ptr(), w._version, tuple(w.shape))
-        hit = self._wcache.get(id(w))
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
+    @staticmethod
+    def _weights(w):
+        """z-space layouts of a [O, C, 4, 4] weight: (forward operand, input-gradient operand).  Built per forward:
+        torch's fused optimizer steps do not bump a parameter's version, so a cross-forward cache could go stale."""
         O, Cc = w.shape[0], w.shape[1]
         wz = w.detach().reshape(O, Cc, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(O, 4, 4 * Cc)   # o, (u,v), (a,b,c)
-        fwd = tap_chunked(wz)                                                                        # K order of the kernels
-        dg = tap_chunked(wz.flip(1).permute(2, 1, 0))                                                # (a,b,c), flipped tap, o
-        self._wcache[id(w)] = (key, fwd, dg)
-        return fwd, dg
+        return tap_chunked(wz), tap_chunked(wz.flip(1).permute(2, 1, 0))                             # (a,b,c), flipped tap, o
 
     def forward(self, x, weights, need_grad):
         """x: [N, C, H, W] (NCHW, as the reference feeds it).  Returns ([N, 1, Ho, Wo] logits, ctx)."""
@@ -48,12 +42,13 @@ class PatchDiscriminatorEngine:
         layers = []
         for w in weights:
             O = w.shape[0]
+            wf, wd = self._weights(w)
             Hz, Wz = _zgrid(vh), _zgrid(vw)
             z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
             K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
             y = torch.empty((N * Hz * Wz, round4(O)), dtype=torch.float32, device=x.device)[:, :O]
-            K.conv(Act(z, N, Hz, Wz), self._weights(w)[0], 2, 1, y, origin=0)
-            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw))
+            K.conv(Act(z, N, Hz, Wz), wf, 2, 1, y, origin=0)
+            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd if need_grad else None))
             src, nchw, Hs, Ws, Cc, slope = y, False, Hz, Wz, O, SLOPE
             vh, vw = vh // 2 + 1, vw // 2 + 1
         out = src.reshape(N, Hs, Ws, Cc)[:, :vh, :vw].permute(0, 3, 1, 2)
@@ -63,7 +58,7 @@ class PatchDiscriminatorEngine:
         """gout: gradient of the [N, 1, Ho, Wo] logits.  Returns (dx NCHW or None, [dw OIHW 4x4] or None)."""
         K = self.K
         layers, N, xshape = ctx
-        z5, C5, Hs5, Ws5, vh5, vw5, Hz, Wz, _ = layers[-1]
+        z5, C5, Hs5, Ws5, vh5, vw5, Hz, Wz, _, _ = layers[-1]
         O = weights[-1].shape[0]
         vh, vw = vh5 // 2 + 1, vw5 // 2 + 1
         dy = torch.zeros((N, Hz, Wz, round4(O)), dtype=torch.float32, device=gout.device)
@@ -72,7 +67,7 @@ class PatchDiscriminatorEngine:
         dws = [None] * len(weights)
         dx = None
         for l in range(len(weights) - 1, -1, -1):
-            z, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw = layers[l]
+            z, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd = layers[l]
             w = weights[l]
             O = w.shape[0]
             if need_w:
@@ -83,7 +78,7 @@ class PatchDiscriminatorEngine:
             if l == 0 and not need_x:
                 break
             dz = torch.empty_like(z)
-            K.conv(Act(dy, N, Hz, Wz), self._weights(w)[1], 2, 1, dz, origin=1)
+            K.conv(Act(dy, N, Hz, Wz), wd, 2, 1, dz, origin=1)
             if nchw:
                 dx = torch.empty(xshape, dtype=torch.float32, device=z.device)
                 K.s2d_bwd(dz, None, 1.0, N, Hs, Ws, Cc, vh, vw, dx, True)

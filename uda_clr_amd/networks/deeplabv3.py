@@ -117,13 +117,6 @@ class DeepLab(Holder):
                 outs.append(self(xr)[0])
         return torch.cat(outs, 0)
 
-    def invalidate_weight_cache(self):
-        """The engine keeps the kernel-side layout of every weight until the parameter's autograd version or storage
-        changes (optimizer steps, ``load_state_dict`` and ``copy_`` all bump it).  In-place writes through ``.data``
-        do not: call this after such a write."""
-        if self._engine is not None:
-            self._engine._wcache.clear()
-
     def _flat_state(self):
         sd = {}
         bb = ("backbone.features", self.backbone.features) if self.backbone_name == 'mobilenet' \

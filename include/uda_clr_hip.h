@@ -144,6 +144,9 @@ int uda_relu_gate(const float* dz, int64_t lddz, const float* z, int64_t ldz, in
  * previous layer's LeakyReLU (slope; 1 = none); uda_s2d_bwd routes dz back to the source grid (zeros outside
  * the valid region), times the LeakyReLU gate read from the sign of z (z_sign NULL = no gate).
  * nchw_*: the source side is an NCHW tensor (the discriminator input / its gradient). */
+/* weight [O, C, 4, 4] -> operand of the ksize-2 uda_conv_fwd on z: dgrad = 0: [O][row over (a,b,c)], wz[o,(u,v),(a,b,c)] =
+ * w[o,c,2u+a,2v+b]; dgrad = 1: [4C][row over o] with flipped taps (its input gradient).  Rows as uda_relayout_ohwi writes them. */
+int uda_relayout_s2d(const float* w, int O, int C, int dgrad, float* out, void* stream);
 int uda_s2d_fwd(const float* src, int64_t ld_src, int nchw_in, int N, int Hs, int Ws, int C, int valid_h,
                 int valid_w, float slope, float* z, int64_t ld_z, int Hz, int Wz, void* stream);
 int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, int Hz, int Wz, float slope, int N, int Hs,

@@ -718,3 +718,16 @@ CASES += [
     ("s2d rows C=64 grid 18x18 valid 17x17", case_s2d(2, 18, 18, 64, False, 17, 17)),
     ("s2d rows C=6 grid 11x9 valid 9x8 (scalar path)", case_s2d(1, 11, 9, 6, False, 9, 8)),
 ]
+
+
+def case_relayout_s2d(O, C, seed=21):
+    def run(dev):
+        w = torch.randn(O, C, 4, 4, generator=gen(seed))
+        K = hip()
+        return max(rel(K.relayout_s2d(w.to(dev), False), SPEC.relayout_s2d(w, False)),
+                   rel(K.relayout_s2d(w.to(dev), True), SPEC.relayout_s2d(w, True))), 0.0
+    return run
+
+
+CASES += [("relayout s2d 64<-2", case_relayout_s2d(64, 2)), ("relayout s2d 128<-64", case_relayout_s2d(128, 64)),
+          ("relayout s2d 1<-512", case_relayout_s2d(1, 512))]

@@ -241,6 +241,13 @@ class SpecKernels:
     def _s2d_grid(src, nchw, N, Hs, Ws, Cc):
         return src if nchw else src.reshape(N, Hs, Ws, Cc).permute(0, 3, 1, 2)
 
+    def relayout_s2d(self, w, dgrad):
+        """z-space operands of a [O, C, 4, 4] weight: wz[o, (u,v), (a,b,c)] = w[o, c, 2u+a, 2v+b] (tap-chunked rows); dgrad:
+        rows (a,b,c), taps flipped, channels o."""
+        O, Cc = w.shape[0], w.shape[1]
+        wz = w.detach().reshape(O, Cc, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(O, 4, 4 * Cc)
+        return tap_chunked(wz.flip(1).permute(2, 1, 0)) if dgrad else tap_chunked(wz)
+
     def s2d_fwd(self, src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z):
         """z[n,i,j,(a,b,c)] = leaky(x[n, 2i+a-2, 2j+b-2, c]) inside the valid vh x vw region, else 0."""
         Hz, Wz = (vh + 5) // 2, (vw + 5) // 2

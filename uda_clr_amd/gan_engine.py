@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from .acts import Act, round4, tap_chunked
+from .acts import Act, round4
 
 SLOPE = 0.2
 
@@ -26,14 +26,6 @@ class PatchDiscriminatorEngine:
     def __init__(self, kernels):
         self.K = kernels
 
-    @staticmethod
-    def _weights(w):
-        """z-space layouts of a [O, C, 4, 4] weight: (forward operand, input-gradient operand).  Built per forward:
-        torch's fused optimizer steps do not bump a parameter's version, so a cross-forward cache could go stale."""
-        O, Cc = w.shape[0], w.shape[1]
-        wz = w.detach().reshape(O, Cc, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(O, 4, 4 * Cc)   # o, (u,v), (a,b,c)
-        return tap_chunked(wz), tap_chunked(wz.flip(1).permute(2, 1, 0))                             # (a,b,c), flipped tap, o
-
     def forward(self, x, weights, need_grad):
         """x: [N, C, H, W] (NCHW, as the reference feeds it).  Returns ([N, 1, Ho, Wo] logits, ctx)."""
         K = self.K
@@ -42,13 +34,16 @@ class PatchDiscriminatorEngine:
         layers = []
         for w in weights:
             O = w.shape[0]
-            wf, wd = self._weights(w)
+            # z-space operands, built per forward (torch's fused optimizer steps do not bump a parameter's version,
+            # so a cross-forward cache could go stale unnoticed)
+            wf = K.relayout_s2d(w, False)
+            wd = K.relayout_s2d(w, True) if need_grad else None
             Hz, Wz = _zgrid(vh), _zgrid(vw)
             z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
             K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
             y = torch.empty((N * Hz * Wz, round4(O)), dtype=torch.float32, device=x.device)[:, :O]
             K.conv(Act(z, N, Hz, Wz), wf, 2, 1, y, origin=0)
-            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd if need_grad else None))
+            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd))
             src, nchw, Hs, Ws, Cc, slope = y, False, Hz, Wz, O, SLOPE
             vh, vw = vh // 2 + 1, vw // 2 + 1
         out = src.reshape(N, Hs, Ws, Cc)[:, :vh, :vw].permute(0, 3, 1, 2)

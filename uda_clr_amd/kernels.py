@@ -65,6 +65,7 @@ SYMBOLS = {
     "uda_rows_stride": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "uda_bn_add_relu": (_I, [C.POINTER(UdaSrc), C.POINTER(UdaSrc), _P, _L, _P]),
     "uda_relu_gate": (_I, [_P, _L, _P, _L, _L, _I, _P, _L, _P]),
+    "uda_relayout_s2d": (_I, [_P, _I, _I, _I, _P, _P]),
     "uda_s2d_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _I, _I, _P]),
     "uda_s2d_bwd": (_I, [_P, _P, _L, _I, _I, _F, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
@@ -339,6 +340,14 @@ class HipKernels:
         self._ck(self.lib.uda_relu_gate(g, ldg, v, ldv, dz.shape[0], dz.shape[1], o, ldo, self._stream()))
 
     # ------------------------------------------------------------------ patch-discriminator geometry
+    def relayout_s2d(self, w, dgrad):
+        O, Cc = w.shape[0], w.shape[1]
+        assert tuple(w.shape[2:]) == (4, 4)
+        out = torch.empty(conv_weight_shape(4 * Cc, 2, O) if dgrad else conv_weight_shape(O, 2, 4 * Cc), dtype=torch.float32,
+                          device=w.device)
+        self._ck(self.lib.uda_relayout_s2d(w.detach().contiguous().data_ptr(), O, Cc, int(bool(dgrad)), out.data_ptr(), self._stream()))
+        return out
+
     def s2d_fwd(self, src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z):
         """src: NCHW tensor (nchw=True) or [N*Hs*Ws, C] rows; z: [N*Hz*Wz, 4C] rows with Hz = (vh+5)//2."""
         self._dev(src)

@@ -321,7 +321,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
 template <int KS, int XF, int TN, int BM>
 static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BN = 64 * TN;
-    constexpr int MW = (BM == 256 || TN % 2 == 0) ? UDA_WS_MATH_WAVES_EVEN : 4;
+    constexpr int MW = BM == 64 ? 4 : ((BM == 256 || TN % 2 == 0) ? UDA_WS_MATH_WAVES_EVEN : 4);
     constexpr size_t lds = 2 * (BM + BN) * IG_LD * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool configured = false;
@@ -349,7 +349,8 @@ static int launch_ws_xf(ConvKArgs& k, int64_t P, hipStream_t st) {
 }
 
 template <int KS>
-static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, bool tall, hipStream_t st) {
+static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, bool tall, bool low, hipStream_t st) {
+    if (low) return launch_ws_xf<KS, 2, 64>(k, P, st);          // 64 x 128 tiles: few pixels (32x32 maps), fill the CUs first
     switch (tn) {
         case 2: return launch_ws_xf<KS, 2, 128>(k, P, st);      // two 128x128 workgroups per CU beat one 256x128 (measured)
         case 3: return launch_ws_xf<KS, 3, 128>(k, P, st);
@@ -379,7 +380,10 @@ int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     // 256-pixel tiles (a third less operand staging per MFMA) once they still fill the chip twice over
     static const int tall_env = getenv("UDA_WS_TALL") ? atoi(getenv("UDA_WS_TALL")) : 1;
     const bool tall = tall_env && best == 4 && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
-    return k.ksize >= 2 ? launch_ws_tn<3>(k, P, best, tall, st) : launch_ws_tn<1>(k, P, best, tall, st);
+    // few pixels (ResNet's 32x32-map layers at B = 8: 64 tiles of 128 rows for 256 CUs): 64-row tiles, twice the workgroups
+    static const int low_env = getenv("UDA_WS_LOW") ? atoi(getenv("UDA_WS_LOW")) : 1;
+    const bool low = low_env && nMt * uda_cdiv(k.Cout, 64 * best) <= 192 && nMt * uda_cdiv(k.Cout, 128) <= 256;
+    return k.ksize >= 2 ? launch_ws_tn<3>(k, P, best, tall, low, st) : launch_ws_tn<1>(k, P, best, tall, low, st);
 }
 
 // ==========================================================================================

@@ -155,12 +155,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU with torch.distributed.run" % (args.gpus, world))
+    if os.environ.get("UDA_CLR_SHARE_GPU"):      # rehearsal of the multi-process path on a one-GPU box (with the gloo backend)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("UDA_CLR_DIST_BACKEND", "nccl")       # nccl = RCCL over xGMI; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from uda_clr_amd.kernels import load_library
     from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator

@@ -16,3 +16,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionstart(session):
+    """A checkout without the built library (the .so is git-ignored): build it once, in-tree, before any test needs it."""
+    lib = os.path.join(ROOT, "uda_clr_amd", "lib", "libuda_clr_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()

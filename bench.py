@@ -168,6 +168,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "uda_clr_amd", "lib", "libuda_clr_hip.so")):
+        if rank == 0:                                   # a checkout without the built library: compile it in-tree first
+            import __graft_entry__
+            __graft_entry__.build()
+        if dist is not None:
+            dist.barrier()
     from uda_clr_amd.kernels import load_library
     from uda_clr_amd.networks.GAN import BoundaryDiscriminator, UncertaintyDiscriminator
     from uda_clr_amd.networks.deeplabv3 import DeepLab

@@ -25,6 +25,7 @@ __all__ = ["DeepLab"]
 class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, need_grad, keys, *tensors):
+        ctx.set_materialize_grads(False)      # unused outputs arrive as None, not as zero tensors to be added
         engine = module._engine_for(x)
         params = module._flat_state()
         masks, module._next_masks = module._next_masks, None

@@ -91,10 +91,11 @@ def train_parity(dev, B=2, S=64, extra_heads=True, backbone="mobilenet"):
     {output: (err vs fp64, fp32-oracle err vs fp64)})."""
     m = seeded_model(perturb=True, backbone=backbone).train()
     gen = torch.Generator().manual_seed(3)
-    x = torch.randn(B, 3, S, S, generator=gen)
-    tmap = (torch.rand(B, 2, S, S, generator=gen) > 0.5).float()
-    tbd = torch.rand(B, 1, S, S, generator=gen)
-    masks = deeplab_ref.draw_masks(B, S, S, gen)
+    SH, SW = (S, S) if isinstance(S, int) else S
+    x = torch.randn(B, 3, SH, SW, generator=gen)
+    tmap = (torch.rand(B, 2, SH, SW, generator=gen) > 0.5).float()
+    tbd = torch.rand(B, 1, SH, SW, generator=gen)
+    masks = deeplab_ref.draw_masks(B, SH, SW, gen)
     wf = [torch.randn(t, generator=gen) for t in (256, 304, 305, 2, 1)]
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
 

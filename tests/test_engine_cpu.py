@@ -144,3 +144,35 @@ def test_mc_fast_path_equals_plain_stochastic_forwards():
             assert int(s0[k]) == int(s1[k]) == 1 + passes, k
         elif k.endswith("running_mean") or k.endswith("running_var"):
             assert _rel(s1[k], s0[k]) < 2e-5, (k, _rel(s1[k], s0[k]))
+
+
+# ------------------------------------------------------------------ edge cases the reference exhibits
+def test_single_image_training_batch_raises_like_the_reference():
+    """quirk Q8: the ASPP image-pooling branch normalises an [N, 256, 1, 1] tensor, so N = 1 in training mode fails in
+    F.batch_norm ("Expected more than 1 value per channel when training"); the product raises the same ValueError."""
+    m = _model().train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m(torch.randn(1, 3, 64, 64))
+    sd = deeplab_ref.canonical_state(m.state_dict())
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        deeplab_ref.deeplab_forward(sd, torch.randn(1, 3, 64, 64), training=True)
+
+
+def test_single_image_eval_and_non_square_input():
+    m = _model().eval()
+    for shape in ((1, 3, 64, 64), (2, 3, 64, 128), (2, 3, 96, 48 + 16)):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(9))
+        with torch.no_grad():
+            mine = m(x)
+            ref = deeplab_ref.deeplab_forward(deeplab_ref.canonical_state(m.state_dict()), x, training=False)
+        for n, a, b in zip(NAMES, mine, ref):
+            assert a.shape == b.shape, (n, shape)
+            assert _rel(a, b) < 2e-4, (n, shape, _rel(a, b))
+
+
+def test_input_size_must_be_a_multiple_of_16():
+    m = _model().eval()
+    with pytest.raises(ValueError, match="multiples of 16"):
+        m(torch.randn(2, 3, 72, 64))
+    with pytest.raises(ValueError, match=r"\[N, 3, H, W\]"):
+        m(torch.randn(2, 1, 64, 64))

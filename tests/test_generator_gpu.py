@@ -104,3 +104,34 @@ def test_mc_fast_path_equals_plain_stochastic_forwards():
             assert int(s0[k]) == int(s1[k]) == 1 + passes
         elif k.endswith("running_mean") or k.endswith("running_var"):
             assert model_cases.rel(s1[k], s0[k]) < 1e-4, k
+
+
+# ---- edge cases
+def test_non_square_and_single_image_eval():
+    from oracle import deeplab_ref
+    m = model_cases.seeded_model(perturb=True).eval()
+    sd = deeplab_ref.canonical_state(m.state_dict())
+    m.to(DEV)
+    for shape in ((1, 3, 64, 64), (2, 3, 64, 128), (2, 3, 96, 64), (3, 3, 160, 32)):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(9))
+        with torch.no_grad():
+            ref = deeplab_ref.deeplab_forward(sd, x, training=False)
+            out = m(x.to(DEV))
+        for n, a, b in zip(model_cases.NAMES, out, ref):
+            assert a.shape == b.shape, (n, shape)
+            assert model_cases.rel(a, b) < 1e-3, (n, shape)
+
+
+def test_single_image_training_batch_raises_like_the_reference():
+    m = model_cases.seeded_model().to(DEV).train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m(torch.randn(1, 3, 64, 64, device=DEV))
+
+
+def test_odd_training_batch_and_non_square_backward():
+    """B = 3, 64 x 96: forward + backward against the fp64 oracle (ragged pixel counts: P is no multiple of any tile)."""
+    fwd, grads, stats, fwd64 = model_cases.train_parity(DEV, B=3, S=(64, 96))
+    assert max(fwd.values()) < 1e-3, fwd
+    bad, gmean = model_cases.grads_ok(grads)
+    assert not bad, list(bad.items())[:10]
+    assert gmean < 4.0, gmean

@@ -75,3 +75,20 @@ def test_forward_follows_fused_optimizer_steps():
         ya, yb = d(x.to(DEV)), ref(x)
     assert (yb - gan_ref.BoundaryDiscriminator()(x)).abs().max() > 0        # the weights really moved
     assert _rel(ya, yb) < 1e-3
+
+
+def test_full_size_batch_independence():
+    """16 x 2 x 512 x 512 (the bench shape): a discriminator has no batch coupling, so logits and input gradients of
+    image k must not depend on the batch it is evaluated in (large-P tiles vs small-P tiles of the same kernels)."""
+    torch.manual_seed(9)
+    d = GAN.UncertaintyDiscriminator().to(DEV)
+    x = torch.rand(16, 2, 512, 512, generator=torch.Generator().manual_seed(13)).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = d(xa)
+    ya.square().sum().backward()
+    for k in (0, 13):
+        xb = x[k:k + 2].clone().requires_grad_(True)
+        yb = d(xb)
+        yb.square().sum().backward()
+        assert _rel(ya[k:k + 2], yb) < 1e-4
+        assert _rel(xa.grad[k:k + 2], xb.grad) < 1e-3

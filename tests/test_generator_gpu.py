@@ -135,3 +135,17 @@ def test_odd_training_batch_and_non_square_backward():
     bad, gmean = model_cases.grads_ok(grads)
     assert not bad, list(bad.items())[:10]
     assert gmean < 4.0, gmean
+
+
+def test_full_size_eval_is_batch_independent():
+    """BASELINE size (16 x 3 x 512 x 512) through a size-independent property: in eval mode every image is processed
+    independently, so image k of the 16-batch (256-row workgroup tiles, 8 math waves) must equal the same image run in a
+    batch of 2 (128-row tiles) - two different kernel configurations of every wide convolution against each other."""
+    m = model_cases.seeded_model(perturb=True).to(DEV).eval()
+    x = torch.randn(16, 3, 512, 512, generator=torch.Generator().manual_seed(12)).to(DEV)
+    with torch.no_grad():
+        big = [t.clone() for t in m(x)]
+        for k in (0, 14):
+            small = m(x[k:k + 2])
+            for n, a, b in zip(model_cases.NAMES, big, small):
+                assert model_cases.rel(a[k:k + 2], b) < 1e-4, (n, k)

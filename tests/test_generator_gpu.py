@@ -149,3 +149,46 @@ def test_full_size_eval_is_batch_independent():
             small = m(x[k:k + 2])
             for n, a, b in zip(model_cases.NAMES, big, small):
                 assert model_cases.rel(a[k:k + 2], b) < 1e-4, (n, k)
+
+
+def test_full_size_backward_agrees_with_forward_differences():
+    """BASELINE size (B = 16, 512 x 512, training mode, fixed dropout masks): the directional derivative of the
+    segmentation loss along the computed gradient must equal the central difference of two more forwards - ties the whole
+    hand-written backward (256-row dgrad tiles, large-P weight-gradient splits, depthwise / BN backward) to the forward path."""
+    from oracle import deeplab_ref
+    import make_golden_inputs
+    B, S = 16, 512
+    m = model_cases.seeded_model(perturb=True).to(DEV).train()
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 3, S, S, generator=gen).to(DEV)
+    tmap, tbd = make_golden_inputs.synth_targets(B, S, S, 22)
+    tmap, tbd = tmap.to(DEV), tbd.to(DEV)
+    masks = deeplab_ref.draw_masks(B, S, S, gen)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    from uda_clr_amd import ops
+
+    def loss_at(shift=None):
+        m.load_state_dict(sd0)
+        if shift is not None:
+            with torch.no_grad():
+                for p, d in zip(params, shift):
+                    p.add_(d)
+        m.set_dropout_masks(masks)
+        out = m(x)
+        return ops.seg_loss(out[0], out[1], tmap, tbd)
+
+    params = [p for p in m.parameters() if p.requires_grad]
+    loss = loss_at()
+    loss.backward()
+    grads = [p.grad.detach().clone() for p in params]
+    gnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).item()
+    res = {}
+    for eps in (1e-3, 2.5e-4):            # the loss is strongly curved along its own gradient: the difference quotient
+        step = [g * (eps / gnorm) for g in grads]      # must approach the analytic slope as the step shrinks
+        with torch.no_grad():
+            lp = loss_at(step).item()
+            lm = loss_at([-s for s in step]).item()
+        res[eps] = (lp - lm) / (2 * eps)
+    an = gnorm
+    assert abs(res[2.5e-4] - an) < 0.02 * an, (res, an)
+    assert abs(res[2.5e-4] - an) <= abs(res[1e-3] - an) + 0.005 * an, (res, an)

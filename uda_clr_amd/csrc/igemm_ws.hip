@@ -145,21 +145,40 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         const int act = a.src.act;
         const float ms = a.src.mask_scale;
         const bool ctail = (C & 3) != 0;
+        const float alo = act == ACT_NONE ? -INFINITY : 0.f, ahi = act == ACT_RELU6 ? 6.f : INFINITY;
+        // prologue on packed pairs (v_pk_fma_f32 / v_pk_mul_f32: half the VALU issue slots, which the loader shares
+        // with the SIMD's MFMA stream - PMC: 3.0 VALU per MFMA with the scalar form of the masked prologue)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc01 = {xf.sc[0], xf.sc[1]}, sc23 = {xf.sc[2], xf.sc[3]};
+        const f32x2 sh01 = {xf.sh[0], xf.sh[1]}, sh23 = {xf.sh[2], xf.sh[3]};
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
             const bool ok = (aok >> i) & 1u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = v[j];
-                if (XF >= 1) {
-                    // multiplier: 0 outside the image, keep-mask * 1/(1-p) inside (v_cvt_f32_ubyteN)
-                    float mul = ok ? 1.f : 0.f;
-                    if (XF == 2) mul = (float)((amask[i] >> (8 * j)) & 0xffu) * ms;   // amask = 0 when !ok
-                    u = uda_act(u * xf.sc[j] + xf.sh[j], act) * mul;
+            if (XF >= 1) {
+                f32x2 t01 = f32x2{v[0], v[1]} * sc01 + sh01, t23 = f32x2{v[2], v[3]} * sc23 + sh23;
+                // none / ReLU / ReLU6 as ONE clamp (v_med3_f32) with per-launch bounds
+                t01 = f32x2{__builtin_amdgcn_fmed3f(t01.x, alo, ahi), __builtin_amdgcn_fmed3f(t01.y, alo, ahi)};
+                t23 = f32x2{__builtin_amdgcn_fmed3f(t23.x, alo, ahi), __builtin_amdgcn_fmed3f(t23.y, alo, ahi)};
+                // multiplier: 0 outside the image, keep-mask * 1/(1-p) inside (v_cvt_f32_ubyteN; amask = 0 when !ok)
+                f32x2 m01, m23;
+                if (XF == 2) {
+                    const uint32_t mk = amask[i];
+                    m01 = f32x2{(float)(mk & 0xffu), (float)((mk >> 8) & 0xffu)} * ms;
+                    m23 = f32x2{(float)((mk >> 16) & 0xffu), (float)(mk >> 24)} * ms;
+                } else {
+                    const float o = ok ? 1.f : 0.f;
+                    m01 = f32x2{o, o};
+                    m23 = m01;
                 }
-                if (ctail && (st_ci + j) >= C) u = 0.f;
-                v[j] = u;
+                t01 *= m01;
+                t23 *= m23;
+                v[0] = t01.x; v[1] = t01.y; v[2] = t23.x; v[3] = t23.y;
+            }
+            if (ctail) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((st_ci + j) >= C) v[j] = 0.f;
             }
             uda_st4(&As[(lrow + 32 * i) * IG_LD + kv], make_float4(v[0], v[1], v[2], v[3]));
         }
@@ -480,20 +499,37 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
             }
             uda_st4(&As[(pr + i * 8) * BM + cv], make_float4(v[0], v[1], v[2], v[3]));
         }
+        // prologue on packed pairs with a one-instruction clamp, as in the forward kernel's loader
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc01 = {xf.sc[0], xf.sc[1]}, sc23 = {xf.sc[2], xf.sc[3]};
+        const f32x2 sh01 = {xf.sh[0], xf.sh[1]}, sh23 = {xf.sh[2], xf.sh[3]};
+        const float alo = act == ACT_NONE ? -INFINITY : 0.f, ahi = act == ACT_RELU6 ? 6.f : INFINITY;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v[4] = {breg[i].x, breg[i].y, breg[i].z, breg[i].w};
             const bool ok = (bok >> i) & 1u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = v[j];
-                if (XF >= 1) {
-                    float mul = ok ? 1.f : 0.f;
-                    if (XF == 2) mul = (float)((bmask[i] >> (8 * j)) & 0xffu) * ms;
-                    u = uda_act(u * xf.sc[j] + xf.sh[j], act) * mul;
+            if (XF >= 1) {
+                f32x2 t01 = f32x2{v[0], v[1]} * sc01 + sh01, t23 = f32x2{v[2], v[3]} * sc23 + sh23;
+                t01 = f32x2{__builtin_amdgcn_fmed3f(t01.x, alo, ahi), __builtin_amdgcn_fmed3f(t01.y, alo, ahi)};
+                t23 = f32x2{__builtin_amdgcn_fmed3f(t23.x, alo, ahi), __builtin_amdgcn_fmed3f(t23.y, alo, ahi)};
+                f32x2 m01, m23;
+                if (XF == 2) {
+                    const uint32_t mk = bmask[i];          // 0 when !ok
+                    m01 = f32x2{(float)(mk & 0xffu), (float)((mk >> 8) & 0xffu)} * ms;
+                    m23 = f32x2{(float)((mk >> 16) & 0xffu), (float)(mk >> 24)} * ms;
+                } else {
+                    const float o = ok ? 1.f : 0.f;
+                    m01 = f32x2{o, o};
+                    m23 = m01;
                 }
-                if (ctail && (ci + j) >= C) u = 0.f;
-                v[j] = u;
+                t01 *= m01;
+                t23 *= m23;
+                v[0] = t01.x; v[1] = t01.y; v[2] = t23.x; v[3] = t23.y;
+            }
+            if (ctail) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((ci + j) >= C) v[j] = 0.f;
             }
             uda_st4(&Bs[(pr + i * 8) * BN + cv], make_float4(v[0], v[1], v[2], v[3]));
         }

@@ -106,18 +106,31 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         const bool has_xf = a.src.scale != nullptr;
         const int act = a.src.act;
         const float ms = a.src.mask_scale;
+        // packed pairs (v_pk_fma / v_pk_mul) and a one-instruction clamp for none / ReLU / ReLU6
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc01 = {xf.sc[0], xf.sc[1]}, sc23 = {xf.sc[2], xf.sc[3]};       // identity when there is no transform
+        const f32x2 sh01 = {xf.sh[0], xf.sh[1]}, sh23 = {xf.sh[2], xf.sh[3]};
+        const float alo = act == ACT_NONE ? -INFINITY : 0.f, ahi = act == ACT_RELU6 ? 6.f : INFINITY;
+        const bool masked = a.src.mask != nullptr;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
             const bool ok = (aok >> i) & 1u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = v[j];
-                if (has_xf) u = u * xf.sc[j] + xf.sh[j];
-                u = uda_act(u, act);
-                if (a.src.mask) u *= ((amask[i] >> (8 * j)) & 0xffu) ? ms : 0.f;
-                v[j] = (ok && (c_ci + j) < C) ? u : 0.f;
+            f32x2 t01 = {areg[i].x, areg[i].y}, t23 = {areg[i].z, areg[i].w};
+            if (has_xf) {
+                t01 = t01 * sc01 + sh01;
+                t23 = t23 * sc23 + sh23;
             }
+            t01 = f32x2{__builtin_amdgcn_fmed3f(t01.x, alo, ahi), __builtin_amdgcn_fmed3f(t01.y, alo, ahi)};
+            t23 = f32x2{__builtin_amdgcn_fmed3f(t23.x, alo, ahi), __builtin_amdgcn_fmed3f(t23.y, alo, ahi)};
+            if (masked) {
+                const uint32_t mk = amask[i];
+                t01 *= f32x2{(float)(mk & 0xffu), (float)((mk >> 8) & 0xffu)} * ms;
+                t23 *= f32x2{(float)((mk >> 16) & 0xffu), (float)(mk >> 24)} * ms;
+            }
+            float v[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(ok && (c_ci + j) < C)) v[j] = 0.f;
             uda_st4(&As[(lrow + 32 * i) * IG_LD + kv], make_float4(v[0], v[1], v[2], v[3]));
         }
 #pragma unroll

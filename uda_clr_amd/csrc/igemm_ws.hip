@@ -94,8 +94,8 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + lrow + 32 * i;
-            boff[i] = n < a.Cout ? n * a.Ktot : -1;
+            const int n = min(n0 + lrow + 32 * i, a.Cout - 1);
+            boff[i] = n * a.Ktot;
         }
     }
 
@@ -113,21 +113,22 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         const int xoff = tapoff * (int)a.src.ldx + ci;
         const int moff = tapoff * (int)a.src.ldm + ci;
         aok = 0;
+        // branch-free: rows outside the image / beyond the channels read element 0 and are zeroed in stage(); weight
+        // rows of the tile padding read the last real row (their output columns are never stored), the K tail of a
+        // 1x1 conv reads the row's last granule against zeroed activations
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const bool ok = kval && ((vmask[i] >> (KS == 3 ? t : 0)) & 1u);
-            areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            amask[i] = 0;
-            if (ok) {
-                areg[i] = uda_ld4(a.src.x + (rowoff[i] + xoff));
-                if (XF == 2) amask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + (rowoffm[i] + moff));
-                aok |= 1u << i;
+            areg[i] = uda_ld4(a.src.x + (ok ? rowoff[i] + xoff : 0));
+            if (XF == 2) {
+                const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.src.mask + (ok ? rowoffm[i] + moff : 0));
+                amask[i] = ok ? mk : 0u;
             }
+            aok |= (ok ? 1u : 0u) << i;
         }
-        const int k0 = kb_cur;
+        const int k0 = min(kb_cur, a.Ktot - 4);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            breg[i] = (k0 < a.Ktot && boff[i] >= 0) ? uda_ld4(a.w + (boff[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < B_IT; ++i) breg[i] = uda_ld4(a.w + (boff[i] + k0));
         kb_cur += IG_BK;
         if (KS == 3) {
             if (++t_cur == a.ksize * a.ksize) {
@@ -175,6 +176,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
                 t23 *= m23;
                 v[0] = t01.x; v[1] = t01.y; v[2] = t23.x; v[3] = t23.y;
             }
+            if (XF == 0 && !ok) v[0] = v[1] = v[2] = v[3] = 0.f;
             if (ctail) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)

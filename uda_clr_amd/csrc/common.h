@@ -31,10 +31,10 @@ static inline int uda_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 #define ACT_RELU 1
 #define ACT_RELU6 2
 
+// none / ReLU / ReLU6 as one clamp (v_med3_f32) between bounds that depend only on the launch's activation code
 __device__ __forceinline__ float uda_act(float v, int act) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-    return v;
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f, hi = act == ACT_RELU6 ? 6.f : INFINITY;
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
 }
 // derivative gate of the activation at pre-activation value a (PyTorch: relu a>0, hardtanh 0<a<6)
 __device__ __forceinline__ float uda_act_gate(float a, int act) {

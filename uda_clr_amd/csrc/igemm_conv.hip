@@ -445,18 +445,29 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
                 if (co + j >= a.Cout) v[j] = 0.f;
             uda_st4(&As[(apr + i * ARPP) * BM + acv], make_float4(v[0], v[1], v[2], v[3]));
         }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));       // packed prologue, as in the forward kernels
+        const f32x2 sc01 = {xf.sc[0], xf.sc[1]}, sc23 = {xf.sc[2], xf.sc[3]};
+        const f32x2 sh01 = {xf.sh[0], xf.sh[1]}, sh23 = {xf.sh[2], xf.sh[3]};
+        const bool masked = a.src.mask != nullptr;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
-            float v[4] = {breg[i].x, breg[i].y, breg[i].z, breg[i].w};
             const bool ok = (bok >> i) & 1u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = v[j];
-                if (has_xf) u = u * xf.sc[j] + xf.sh[j];
-                u = uda_act(u, act);
-                if (a.src.mask) u *= ((bmask[i] >> (8 * j)) & 0xffu) ? ms : 0.f;
-                v[j] = (ok && (ci + j) < C) ? u : 0.f;
+            f32x2 t01 = {breg[i].x, breg[i].y}, t23 = {breg[i].z, breg[i].w};
+            if (has_xf) {
+                t01 = t01 * sc01 + sh01;
+                t23 = t23 * sc23 + sh23;
             }
+            t01 = f32x2{uda_act(t01.x, act), uda_act(t01.y, act)};
+            t23 = f32x2{uda_act(t23.x, act), uda_act(t23.y, act)};
+            if (masked) {
+                const uint32_t mk = bmask[i];
+                t01 *= f32x2{(float)(mk & 0xffu), (float)((mk >> 8) & 0xffu)} * ms;
+                t23 *= f32x2{(float)((mk >> 16) & 0xffu), (float)(mk >> 24)} * ms;
+            }
+            float v[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(ok && (ci + j) < C)) v[j] = 0.f;
             uda_st4(&Bs[(bpr + i * BRPP) * BN + bjv], make_float4(v[0], v[1], v[2], v[3]));
         }
     };

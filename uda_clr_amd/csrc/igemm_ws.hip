@@ -99,6 +99,15 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         }
     }
 
+    // Operand loads go through buffer descriptors: a lane whose tap falls outside the image (or beyond the channels)
+    // presents an out-of-range offset and the hardware returns zeros - no branch, no select, no memory access.
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (P * a.src.ldx) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.src.mask ? a.src.mask : reinterpret_cast<const uint8_t*>(a.src.x)), 0,
+        a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+
     auto issue = [&]() {       // loads of the chunk at (t_cur, ci_cur); then advance by BK
         const int t = t_cur, ci = ci_cur;
         const bool kval = ci < a.Kc;
@@ -113,17 +122,13 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         const int xoff = tapoff * (int)a.src.ldx + ci;
         const int moff = tapoff * (int)a.src.ldm + ci;
         aok = 0;
-        // branch-free: rows outside the image / beyond the channels read element 0 and are zeroed in stage(); weight
-        // rows of the tile padding read the last real row (their output columns are never stored), the K tail of a
-        // 1x1 conv reads the row's last granule against zeroed activations
+        // weight rows of the tile padding read the last real row (their output columns are never stored), the K tail
+        // of a 1x1 conv reads the row's last granule against zeroed activations
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const bool ok = kval && ((vmask[i] >> (KS == 3 ? t : 0)) & 1u);
-            areg[i] = uda_ld4(a.src.x + (ok ? rowoff[i] + xoff : 0));
-            if (XF == 2) {
-                const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.src.mask + (ok ? rowoffm[i] + moff : 0));
-                amask[i] = ok ? mk : 0u;
-            }
+            areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (rowoff[i] + xoff) * 4 : OOB, 0, 0));
+            if (XF == 2) amask[i] = __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? rowoffm[i] + moff : OOB, 0, 0);
             aok |= (ok ? 1u : 0u) << i;
         }
         const int k0 = min(kb_cur, a.Ktot - 4);
@@ -176,7 +181,6 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
                 t23 *= m23;
                 v[0] = t01.x; v[1] = t01.y; v[2] = t23.x; v[3] = t23.y;
             }
-            if (XF == 0 && !ok) v[0] = v[1] = v[2] = v[3] = 0.f;
             if (ctail) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -382,7 +386,7 @@ static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, bool tall, bool low, hi
 
 int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     const int64_t lim = (int64_t)1 << 31;
-    UDA_REQUIRE((P + 128) * k.src.ldx < lim && (P + 128) * (k.src.mask ? k.src.ldm : 1) < lim && (int64_t)(k.Cout + 320) * k.Ktot < lim,
+    UDA_REQUIRE((P + 128) * k.src.ldx < lim / 4 && (P + 128) * (k.src.mask ? k.src.ldm : 1) < lim && (int64_t)(k.Cout + 320) * k.Ktot < lim,
                 "uda_conv_fwd: operand too large for the 32-bit element offsets of the wide-tile kernel");
     // Tile width BN = 64*TN chosen by a wave-quantisation model: workgroups run one per CU, a K-chunk
     // costs ~TN MFMA-units, so time ~ ceil(#tiles / 256 CUs) * TN.  E.g. Cout = 304 at P = 262144 ->

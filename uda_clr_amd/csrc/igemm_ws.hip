@@ -468,21 +468,29 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     const int ldx = (int)a.src.ldx, ldm = (int)a.src.ldm, lddy = (int)a.lddy;
     const int tapoff = dh * W + dw;
 
+    // buffer descriptors: lanes outside the pixel range / the image / the channel range present an out-of-range offset
+    // and receive zeros from the hardware (no branches, no selects)
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy), 0, (int)min((int64_t)0x7fffffff, (P * a.lddy) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (P * a.src.ldx) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.src.mask ? a.src.mask : reinterpret_cast<const uint8_t*>(a.src.x)), 0,
+        a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
     auto issue = [&]() {
         bok = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool pin = pp[i] < (int)P;
-            areg[i] = (pin && co < a.Cout) ? uda_ld4(a.dy + (pp[i] * lddy + co)) : make_float4(0.f, 0.f, 0.f, 0.f);
-            breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            bmask[i] = 0;
+            areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                yres, (pin && co < a.Cout) ? (pp[i] * lddy + co) * 4 : OOB, 0, 0));
             const int hh = hh0[i] + dh, ww = ww0[i] + dw;
-            if (jok && pin && hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                const int q = pp[i] + tapoff;
-                breg[i] = uda_ld4(a.src.x + (q * ldx + ci));
-                if (XF == 2) bmask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + (q * ldm + ci));
-                bok |= 1u << i;
-            }
+            const bool ok = jok && pin && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const int q = pp[i] + tapoff;
+            breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (q * ldx + ci) * 4 : OOB, 0, 0));
+            if (XF == 2) bmask[i] = __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * ldm + ci : OOB, 0, 0);
+            bok |= (ok ? 1u : 0u) << i;
             // advance this row by one chunk (32 pixels)
             pp[i] += WG_BKP;
             ww0[i] += WG_BKP;

@@ -74,6 +74,7 @@ conv_case("dgrad3x3 256->304 128^2", B, 128, 128, 256, 304, 3, 1, stats=False)
 conv_case("conv3x3 320->256 32^2 dil6 (aspp)", B, 32, 32, 320, 256, 3, 6)
 conv_case("conv1x1 1280->256 32^2 lazy (aspp.conv1)", B, 32, 32, 1280, 256, 1, 1, True)
 conv_case("conv1x1 16->96 256^2 (expand)", B, 256, 256, 16, 96, 1, 1)
+conv_case("conv1x1 16->96 256^2 (expand) no stats", B, 256, 256, 16, 96, 1, 1, stats=False)
 conv_case("conv1x1 96->24 128^2 lazy (project)", B, 128, 128, 96, 24, 1, 1, True)
 conv_case("conv1x1 144->24 128^2 lazy (project)", B, 128, 128, 144, 24, 1, 1, True)
 conv_case("conv1x1 24->144 128^2 (expand)", B, 128, 128, 24, 144, 1, 1)

@@ -66,5 +66,6 @@ __device__ __forceinline__ void uda_load_xf4(Xf4& t, const float* scale, const f
     }
 }
 
+__device__ __forceinline__ bool uda_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ float4 uda_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void uda_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

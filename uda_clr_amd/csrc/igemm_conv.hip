@@ -21,6 +21,7 @@
 //   Tiles are ordered n-fastest and XCD-chunked (uda_xcd_remap) so the two N tiles of a pixel
 //   tile and spatially adjacent pixel tiles share one XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 #include "igemm_args.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +64,13 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     int c_ci = 0;
     bool c_kval = false;
 
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (P * a.src.ldx) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.src.mask ? a.src.mask : reinterpret_cast<const uint8_t*>(a.src.x)), 0,
+        a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+
     auto issue = [&](int chunk) {
         const int k0 = chunk * IG_BK + kv;          // position in the weight row
         int t = 0, ci = k0;
@@ -85,14 +93,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         for (int i = 0; i < A_IT; ++i) {
             const int hh = ph[i] + dh, ww = pw[i] + dw;
             const bool ok = c_kval && pok[i] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            amask[i] = 0x01010101u;
-            if (ok) {
-                const int64_t q = m0 + lrow + 32 * i + (int64_t)dh * W + dw;
-                areg[i] = uda_ld4(a.src.x + q * a.src.ldx + ci);
-                if (a.src.mask) amask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + q * a.src.ldm + ci);
-                aok |= 1u << i;
-            }
+            // buffer loads: an out-of-range offset returns zeros (no branch around the load)
+            const int q = (int)(m0 + lrow + 32 * i) + dh * W + dw;
+            areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (q * (int)a.src.ldx + ci) * 4 : OOB, 0, 0));
+            amask[i] = a.src.mask ? __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * (int)a.src.ldm + ci : OOB, 0, 0) : 0x01010101u;
+            aok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -177,8 +182,13 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         }
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Each 32x32 block goes through a per-wave LDS patch and leaves as 16-byte stores (8 rows x 128 B per
+    // instruction instead of 2 rows x 128 B with 4-byte stores: the short-K convs are bound by their output).
     const int colb = n0 + wn * TN * 32 + (lane & 31);
+    const bool vec_ok = uda_aligned16_dev(a.y) && (a.ldy & 3) == 0 && (!a.addend || (uda_aligned16_dev(a.addend) && (a.ld_add & 3) == 0));
+    __syncthreads();                       // every wave is done with the operand tiles: smem becomes staging space
+    float* patch = smem + wave * (32 * IG_LD);
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -189,15 +199,41 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int64_t rbase = m0 + wm * TM * 32 + 32 * i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * TM * 32 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (cok && row < P) {
-                    float v = acc[i][j][r] + bv;
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = acc[i][j][r] + bv;
+                if (cok && rbase + rl < P) {
                     s1[j] += v;
                     s2[j] += v * v;
-                    if (a.addend) v += a.addend[row * a.ld_add + col];
-                    a.y[row * a.ldy + col] = v;
+                }
+                if (vec_ok) {
+                    patch[rl * IG_LD + (lane & 31)] = v;
+                } else if (cok && rbase + rl < P) {
+                    a.y[(rbase + rl) * a.ldy + col] = a.addend ? v + a.addend[(rbase + rl) * a.ld_add + col] : v;
+                }
+            }
+            if (vec_ok) {
+                const int cb = n0 + wn * TN * 32 + 32 * j + (lane & 7) * 4;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int rl = rq * 8 + (lane >> 3);
+                    const int64_t row = rbase + rl;
+                    float4 o = uda_ld4(&patch[rl * IG_LD + (lane & 7) * 4]);
+                    if (row < P && cb < a.Cout) {
+                        if (cb + 3 < a.Cout) {
+                            if (a.addend) {
+                                const float4 ad = uda_ld4(a.addend + row * a.ld_add + cb);
+                                o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                            }
+                            uda_st4(a.y + row * a.ldy + cb, o);
+                        } else {
+                            const float ov[4] = {o.x, o.y, o.z, o.w};
+                            for (int q = 0; q < 4; ++q)
+                                if (cb + q < a.Cout) a.y[row * a.ldy + cb + q] = a.addend ? ov[q] + a.addend[row * a.ld_add + cb + q] : ov[q];
+                        }
+                    }
                 }
             }
         }
@@ -348,6 +384,8 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.ldy = a->ldy;
     k.stats = a->stats;
     k.debug = 0;
+    UDA_REQUIRE((P + 128) * a->src.ldx < ((int64_t)1 << 29) && (P + 128) * (a->src.mask ? a->src.ldm : 1) < ((int64_t)1 << 31),
+                "uda_conv_fwd: operand too large for 32-bit byte offsets (P * ld must stay below 2^29 elements)");
     int e;
     if (a->Cout == 1 && !a->src.scale && !a->src.mask && a->src.act == ACT_NONE && !a->stats && k.Ktot >= 1024) {
         hipLaunchKernelGGL(conv_cout1_kernel, dim3(uda_cdiv(P, 4)), dim3(256), 0, st, k);
@@ -357,7 +395,14 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
-    else if (k.Ktot <= 192) e = launch_conv<2, 2, 2, 2>(k, P, st);     // short K: HBM-bound, single-role tiles
+    else if (k.Ktot <= 192) {
+        // short K (the backbone's expand convs): output-bound; pick the tile width that wastes the fewest columns
+        // (Cout = 144 -> one 160-wide tile instead of two 128-wide ones, 576 -> six 96-wide tiles, ...)
+        const int w96 = uda_cdiv(a->Cout, 96) * 96, w128 = uda_cdiv(a->Cout, 128) * 128, w160 = uda_cdiv(a->Cout, 160) * 160;
+        if (w160 <= w128 && w160 <= w96) e = launch_conv<1, 5, 4, 1>(k, P, st);
+        else if (w128 <= w96) e = launch_conv<2, 2, 2, 2>(k, P, st);
+        else e = launch_conv<1, 3, 4, 1>(k, P, st);
+    }
     else e = launch_conv_ws(k, P, st);
     return e;
 }

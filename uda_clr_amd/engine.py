@@ -160,7 +160,8 @@ class GeneratorEngine:
         if ck not in ctx.w_cache:
             w = ctx.params[key]
             ctx.w_cache[ck] = {"ohwi": self.K.relayout_ohwi, "dgrad": self.K.relayout_dgrad,
-                               "dw": self.K.relayout_dw}[kind](w)
+                               "dw": self.K.relayout_dw,
+                               "dwflip": lambda t: self.K.relayout_dw(t).flip(0).contiguous()}[kind](w)
         return ctx.w_cache[ck]
 
     def _bn(self, ctx, prefix, stats, count, training, scale, shift, mean=None, invstd=None,
@@ -390,7 +391,12 @@ class GeneratorEngine:
             K.dwconv_wgrad(e, dyd, stride, dil, r["border"], dwg)
             G[pre + kd + ".weight"] = dwg
             dUe = self._buf(x, zin.P, d.C)
-            K.dwconv_dgrad(dyd, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, N, Hi, Wi, dUe)
+            if stride == 1:
+                # the input gradient of a stride-1 depthwise conv IS a depthwise conv of dy with the taps reversed:
+                # runs on the LDS-tiled forward kernel (the flat gather kernel stays for the four stride-2 blocks)
+                K.dwconv_fwd(Act(dyd, N, Hi, Wi), self._w(ctx, pre + kd + ".weight", "dwflip"), 1, dil, 0, dUe, None)
+            else:
+                K.dwconv_dgrad(dyd, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, N, Hi, Wi, dUe)
             del dUd, dyd, dyp
             if t != 1:
                 dye = self._bn_backward(ctx, G, e, dUe)

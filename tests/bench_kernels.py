@@ -87,7 +87,7 @@ wgrad_case("wgrad1x1 1280->256 32^2 lazy", B, 32, 32, 1280, 256, 1, 1, True)
 
 
 def ew_cases():
-    for (Cc, H) in ((96, 256), (144, 128), (24, 128), (384, 32)):      # backbone shapes: no mask, relu6
+    for (Cc, H) in ((96, 256), (144, 128), (24, 128), (384, 32), (960, 32), (576, 32), (305, 128)):      # backbone shapes: no mask, relu6
         P = B * H * H
         y = src(B, H, H, Cc, True, False)
         y.act = ACT_RELU6

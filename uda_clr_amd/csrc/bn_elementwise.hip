@@ -15,6 +15,10 @@ int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hi
 
 #define RED_ITER 32
 #define RED_CBLK 1024
+// channel block of the column REDUCTIONS: 128 channels per workgroup (8 pixel lanes x RED_ITER pixels): every
+// workgroup ends with 3 x Cb fp64 atomics, so wide layers (C = 576, 960, 1024) must not put one pixel lane on 1024
+// channels (2880 atomics per 32 pixels); channels beyond 128 go to blockIdx.y
+#define RED_CBLK_SUM 128
 
 __device__ __forceinline__ void st4_guard(float* p, const float v[4], int nvalid) {
     if (nvalid >= 4) {
@@ -252,8 +256,8 @@ struct RedArgs {
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
     __shared__ float red[3 * 1024];
-    const int cblk0 = blockIdx.y * RED_CBLK;
-    const int Cb = min(RED_CBLK, a.C - cblk0);
+    const int cblk0 = blockIdx.y * RED_CBLK_SUM;
+    const int Cb = min(RED_CBLK_SUM, a.C - cblk0);
     const int G = (Cb + 3) >> 2, PP = 256 / G;
     const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
     const bool active = pl < PP;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
 }
 
 static inline int red_nwg(int64_t P, int C) {
-    const int Cb = C < RED_CBLK ? C : RED_CBLK;
+    const int Cb = C < RED_CBLK_SUM ? C : RED_CBLK_SUM;
     const int PP = 256 / ((Cb + 3) / 4);
     return uda_cdiv(P, (int64_t)PP * RED_ITER);
 }
@@ -334,7 +338,7 @@ extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int n
     RedArgs a;
     a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.out = out;
     const int nwg = red_nwg(P, C);
-    hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nwg, uda_cdiv(C, RED_CBLK)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nwg, uda_cdiv(C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("colstats");
     return 0;
 }
@@ -349,7 +353,7 @@ extern "C" int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y
     RedArgs a;
     a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.out = sums;
     const int nwg = red_nwg(P, y->C);
-    hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nwg, uda_cdiv(y->C, RED_CBLK)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nwg, uda_cdiv(y->C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("bnbwd_reduce");
     return 0;
 }

@@ -54,7 +54,8 @@ int uda_version(void);
 /* ---- weight re-layouts (tiny; once per step).  torch layout OIHW in. */
 /* K order of one weight row: k = 1: [round4(I)];  k > 1 ("tap-chunked"): [nCC][k*k][32] with nCC = ceil(round4(I)/32),
  * i.e. element (tap t, channel c) at ((c/32)*k*k + t)*32 + c%32, zero padded: all taps of one 32-channel slice are
- * consecutive K-chunks of the implicit GEMM, so a workgroup re-reads its pixel strip while it is L2-resident.
+ * consecutive K-chunks of the implicit GEMM, so a workgroup re-reads its pixel strip while it is L2-resident;
+ * with round4(I) < 32 the row stays tap-major and unpadded, [k*k][round4(I)].
  * out[O][row as above]                              - operand of uda_conv_fwd              */
 int uda_relayout_ohwi(const float* w, int O, int I, int k, float* out, void* stream);
 /* out[I][row over O as above], taps flipped        - operand of uda_conv_fwd used as dgrad */

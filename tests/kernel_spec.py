@@ -98,7 +98,7 @@ class SpecKernels:
     def _taps_channels(w, T, Cin):
         """inverse of the weight layout: [R, T, Cin]"""
         R = w.shape[0]
-        if T == 1:
+        if T == 1 or round4(Cin) < K_CHUNK:
             return w[:, :, :Cin]
         ncc = w.shape[1] // T
         return w.reshape(R, ncc, T, K_CHUNK).permute(0, 2, 1, 3).reshape(R, T, ncc * K_CHUNK)[:, :, :Cin]

@@ -86,8 +86,13 @@ K_CHUNK = 32      # IG_BK of the implicit-GEMM kernels
 def tap_chunked(w_rtc: torch.Tensor) -> torch.Tensor:
     """[R, T, C] (rows, taps, channels) -> the K order of the multi-tap implicit-GEMM kernels, [R, nCC*T, 32]:
     k = (cc*T + t)*32 + c % 32 with cc = c // 32, channels zero-padded to a multiple of 32.  All T taps of one
-    32-channel slice are consecutive K-chunks, so a workgroup re-reads its pixel strip while it is L2-resident."""
+    32-channel slice are consecutive K-chunks, so a workgroup re-reads its pixel strip while it is L2-resident.
+    With fewer than 32 channels the order stays tap-major, [R, T, round4(C)] (nothing to keep resident, no padding)."""
     R, T, Cc = w_rtc.shape
+    if round4(Cc) < K_CHUNK:                  # fewer than 32 channels: tap-major, padded to round4(C) only
+        out = w_rtc.new_zeros(R, T, round4(Cc))
+        out[:, :, :Cc] = w_rtc
+        return out
     ncc = (Cc + K_CHUNK - 1) // K_CHUNK
     out = w_rtc.new_zeros(R, T, ncc * K_CHUNK)
     out[:, :, :Cc] = w_rtc
@@ -96,6 +101,6 @@ def tap_chunked(w_rtc: torch.Tensor) -> torch.Tensor:
 
 def conv_weight_shape(rows: int, ksize: int, channels: int):
     """Shape of the relayouted weight operand of ``conv``: [rows, 1, round4(C)] for 1x1, tap-chunked otherwise."""
-    if ksize == 1:
-        return (rows, 1, round4(channels))
+    if ksize == 1 or round4(channels) < K_CHUNK:
+        return (rows, ksize * ksize, round4(channels))
     return (rows, ((channels + K_CHUNK - 1) // K_CHUNK) * ksize * ksize, K_CHUNK)

@@ -153,11 +153,13 @@ extern "C" int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, i
 // (k = (cc*4 + t)*32 + q % 32, cc = q / 32 over the operand's channel index q, zero padded to a multiple of 32):
 //   forward : rows o,       taps t = (u, v),          channels q = (a, b, c):  w[o, c, 2u+a, 2v+b]
 //   dgrad   : rows (a,b,c), taps t = 3 - (u, v) flip, channels q = o        :  the same element
-__global__ void relayout_s2d_kernel(const float* __restrict__ w, int O, int C, int dgrad, int Kr, int64_t total,
+__global__ void relayout_s2d_kernel(const float* __restrict__ w, int O, int C, int dgrad, int Kr, int Kc, int64_t total,
                                     float* __restrict__ out) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(e % Kr), row = (int)(e / Kr);
-        const int chunk = k >> 5, t = chunk & 3, q = (chunk >> 2) * 32 + (k & 31);
+        int t, q;
+        if (Kc < 32) { t = k / Kc; q = k - t * Kc; }          // fewer than 32 channels: tap-major, unpadded
+        else { const int chunk = k >> 5; t = chunk & 3; q = (chunk >> 2) * 32 + (k & 31); }
         int o, abc, uv;
         if (!dgrad) { o = row; abc = q; uv = t; }
         else { o = q; abc = row; uv = 3 - t; }
@@ -174,10 +176,11 @@ __global__ void relayout_s2d_kernel(const float* __restrict__ w, int O, int C, i
 extern "C" int uda_relayout_s2d(const float* w, int O, int C, int dgrad, float* out, void* stream) {
     UDA_REQUIRE(w && out && O > 0 && C > 0, "uda_relayout_s2d: bad args");
     const int chan = dgrad ? O : 4 * C, rows = dgrad ? 4 * C : O;
-    const int Kr = ((((chan + 3) / 4) * 4 + 31) / 32) * 4 * 32;
+    const int Kc = ((chan + 3) / 4) * 4;
+    const int Kr = Kc < 32 ? 4 * Kc : ((Kc + 31) / 32) * 4 * 32;
     const int64_t total = (int64_t)rows * Kr;
     const int grid = (int)(uda_cdiv(total, 256) > 8192 ? 8192 : uda_cdiv(total, 256));
-    hipLaunchKernelGGL(relayout_s2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, O, C, dgrad, Kr, total, out);
+    hipLaunchKernelGGL(relayout_s2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, O, C, dgrad, Kr, Kc, total, out);
     UDA_LAUNCH_CHECK("relayout_s2d");
     return 0;
 }

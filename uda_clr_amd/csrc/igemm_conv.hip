@@ -74,10 +74,15 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     auto issue = [&](int chunk) {
         const int k0 = chunk * IG_BK + kv;          // position in the weight row
         int t = 0, ci = k0;
-        if (a.ksize >= 2) {                          // tap-chunked K: chunk = cc * T + t
-            const int T = a.ksize * a.ksize;
-            t = chunk % T;
-            ci = (chunk / T) * IG_BK + kv;
+        if (a.ksize >= 2) {
+            if (a.Kc >= IG_BK) {                     // tap-chunked K: chunk = cc * T + t
+                const int T = a.ksize * a.ksize;
+                t = chunk % T;
+                ci = (chunk / T) * IG_BK + kv;
+            } else {                                 // fewer than 32 channels: k = t * Kc + ci
+                t = k0 / a.Kc;
+                ci = k0 - t * a.Kc;
+            }
         }
         c_kval = k0 < a.Ktot && ci < a.Kc;
         c_ci = ci;
@@ -296,7 +301,8 @@ int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hi
 // floats per weight row of a conv with C input channels and ksize x ksize taps
 static inline int uda_k_row(int C, int ksize) {
     const int Kc = ((C + 3) / 4) * 4;
-    return ksize == 1 ? Kc : ((Kc + IG_BK - 1) / IG_BK) * ksize * ksize * IG_BK;
+    if (ksize == 1 || Kc < IG_BK) return ksize * ksize * Kc;      // fewer than 32 channels: tap-major, unpadded
+    return ((Kc + IG_BK - 1) / IG_BK) * ksize * ksize * IG_BK;
 }
 
 static int check_src(const uda_src_t& s, const char* who) {
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvKArgs a) {
         const float* xr = a.src.x + (p + (int64_t)(hh - ph) * W + (ww - pw)) * a.src.ldx;
         for (int c = lane * 4; c < a.Kc; c += 256) {
             // tap-chunked weight row (T > 1): k = ((c / 32) * T + t) * 32 + c % 32; zero beyond C
-            const int kq = T == 1 ? c : ((c / IG_BK) * T + t) * IG_BK + (c % IG_BK);
+            const int kq = (T == 1 || a.Kc < IG_BK) ? t * a.Kc + c : ((c / IG_BK) * T + t) * IG_BK + (c % IG_BK);
             const float4 xv = uda_ld4(xr + c), wv = uda_ld4(a.w + kq);
             float s = xv.x * wv.x;
             if (c + 1 < a.src.C) s += xv.y * wv.y;
@@ -395,7 +401,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
-    else if (k.Ktot <= 192) {
+    else if (k.Ktot <= 192 || (a->ksize >= 2 && k.Kc < IG_BK)) {     // (the wide-tile kernel only walks the tap-chunked K order)
         // short K (the backbone's expand convs): output-bound; pick the tile width that wastes the fewest columns
         // (Cout = 144 -> one 160-wide tile instead of two 128-wide ones, 576 -> six 96-wide tiles, ...)
         const int w96 = uda_cdiv(a->Cout, 96) * 96, w128 = uda_cdiv(a->Cout, 128) * 128, w160 = uda_cdiv(a->Cout, 160) * 160;
@@ -679,13 +685,16 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
 // cc = c / 32, channels zero-padded to a multiple of 32: all T taps of one 32-channel slice are consecutive
 // K-chunks, so a workgroup re-reads its pixel strip while it is still L2-resident (the tap-major order re-read it from
 // the memory side: 5x the algorithmic bytes on FETCH_SIZE).
-__device__ __forceinline__ void uda_k_decode(int64_t e, int T, int Kr, int& c, int& t, int& row) {
-    // e indexes [row][Kr]; Kr = Kc (T == 1) or nCC*T*32
+__device__ __forceinline__ void uda_k_decode(int64_t e, int T, int Kr, int Kc, int& c, int& t, int& row) {
+    // e indexes [row][Kr]; Kr = Kc (T == 1), T*Kc (fewer than 32 channels: tap-major, no padding) or nCC*T*32
     const int k = (int)(e % Kr);
     row = (int)(e / Kr);
     if (T == 1) {
         c = k;
         t = 0;
+    } else if (Kc < IG_BK) {
+        t = k / Kc;
+        c = k - t * Kc;
     } else {
         const int chunk = k / IG_BK;
         t = chunk % T;
@@ -694,17 +703,19 @@ __device__ __forceinline__ void uda_k_decode(int64_t e, int T, int Kr, int& c, i
 }
 __global__ void relayout_ohwi_kernel(const float* __restrict__ w, int O, int I, int T, int Kr, float* __restrict__ out) {
     const int64_t total = (int64_t)O * Kr;
+    const int Kc = ((I + 3) / 4) * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int ci, t, o;
-        uda_k_decode(e, T, Kr, ci, t, o);
+        uda_k_decode(e, T, Kr, Kc, ci, t, o);
         out[e] = ci < I ? w[((int64_t)o * I + ci) * T + t] : 0.f;
     }
 }
 __global__ void relayout_dgrad_kernel(const float* __restrict__ w, int O, int I, int T, int Kr, float* __restrict__ out) {
     const int64_t total = (int64_t)I * Kr;
+    const int Kc = ((O + 3) / 4) * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int o, t, ci;
-        uda_k_decode(e, T, Kr, o, t, ci);
+        uda_k_decode(e, T, Kr, Kc, o, t, ci);
         out[e] = o < O ? w[((int64_t)o * I + ci) * T + (T - 1 - t)] : 0.f;
     }
 }

@@ -419,15 +419,18 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
 // of 32 consecutive dwords.  The pixel range is split over blockIdx.y; every split writes its
 // own fp32 slab and a second kernel sums the slabs (bitwise reproducible, no float atomics).
 
+// pixels per K-chunk of the narrow (HBM-bound) weight-gradient kernel: one barrier pair per 64 pixels
+#define WGN_BKP 64
+
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int AV = BM / 4, BV = BN / 4;                 // float4 per staged row
     constexpr int ARPP = 256 / AV, BRPP = 256 / BV;          // pixel rows per pass
-    constexpr int APASS = WG_BKP / ARPP, BPASS = WG_BKP / BRPP;
-    __shared__ __attribute__((aligned(16))) float smem[WG_BKP * (BM + BN)];
+    constexpr int APASS = WGN_BKP / ARPP, BPASS = WGN_BKP / BRPP;
+    __shared__ __attribute__((aligned(16))) float smem[WGN_BKP * (BM + BN)];
     float* As = smem;                    // [32][BM]
-    float* Bs = smem + WG_BKP * BM;      // [32][BN]
+    float* Bs = smem + WGN_BKP * BM;      // [32][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
     unsigned bok = 0;
 
     auto issue = [&](int chunk) {
-        const int64_t p0 = (int64_t)chunk * WG_BKP;
+        const int64_t p0 = (int64_t)chunk * WGN_BKP;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int64_t p = p0 + apr + i * ARPP;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
         __syncthreads();
         if (c + 1 < c1) issue(c + 1);
 #pragma unroll
-        for (int kk = 0; kk < WG_BKP / 2; ++kk) {
+        for (int kk = 0; kk < WGN_BKP / 2; ++kk) {
             float af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + kh) * BM + acol + 32 * i];
@@ -622,7 +625,7 @@ static WgradPlan wgrad_plan(int64_t P, int Cout, int Cin, int ksize) {
     else { p.bm = 128; p.bn = 128; }
     p.nCot = uda_cdiv(Cout, p.bm);
     p.nJt = uda_cdiv(J, p.bn);
-    p.nchunks = uda_cdiv(P, WG_BKP);
+    p.nchunks = uda_cdiv(P, (p.bm == 128 && p.bn == 128) ? WG_BKP : WGN_BKP);
     int S = 1024 / (p.nCot * p.nJt);
     if (S > p.nchunks / 4) S = p.nchunks / 4;
     if (S < 1) S = 1;

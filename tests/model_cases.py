@@ -59,9 +59,9 @@ def grads_ok(grads):
     return bad, gmean
 
 
-def seeded_model(seed=1337, perturb=False, backbone="mobilenet"):
+def seeded_model(seed=1337, perturb=False, backbone="mobilenet", output_stride=16):
     torch.manual_seed(seed)
-    m = DeepLab(num_classes=2, backbone=backbone, output_stride=16, sync_bn=True, freeze_bn=False,
+    m = DeepLab(num_classes=2, backbone=backbone, output_stride=output_stride, sync_bn=True, freeze_bn=False,
                 method="prototype_full")
     if perturb:
         g = torch.Generator().manual_seed(5)
@@ -89,17 +89,19 @@ def eval_parity(dev, B=2, S=64, perturb=True, backbone="mobilenet"):
     return {n: rel(a, b) for n, a, b in zip(NAMES, out, ref)}
 
 
-def train_parity(dev, B=2, S=64, extra_heads=True, backbone="mobilenet"):
+def train_parity(dev, B=2, S=64, extra_heads=True, backbone="mobilenet", output_stride=16):
     """HIP training forward + backward (injected dropout masks) vs the fp64 oracle.  Returns
     (forward errs vs fp32 oracle, {param: (err vs fp64, fp32-oracle err vs fp64)}, running-stat err,
     {output: (err vs fp64, fp32-oracle err vs fp64)})."""
-    m = seeded_model(perturb=True, backbone=backbone).train()
+    m = seeded_model(perturb=True, backbone=backbone, output_stride=output_stride).train()
     gen = torch.Generator().manual_seed(3)
     SH, SW = (S, S) if isinstance(S, int) else S
     x = torch.randn(B, 3, SH, SW, generator=gen)
     tmap = (torch.rand(B, 2, SH, SW, generator=gen) > 0.5).float()
     tbd = torch.rand(B, 1, SH, SW, generator=gen)
     masks = deeplab_ref.draw_masks(B, SH, SW, gen)
+    if output_stride == 8:          # the ASPP output (and its dropout mask) lives at 1/8 resolution
+        masks["aspp.dropout"] = (torch.rand(B, 256, SH // 8, SW // 8, generator=gen) >= 0.5).to(torch.uint8)
     wf = [torch.randn(t, generator=gen) for t in (256, 304, 305, 2, 1)]
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
 
@@ -111,11 +113,11 @@ def train_parity(dev, B=2, S=64, extra_heads=True, backbone="mobilenet"):
         return loss
 
     o32 = deeplab_ref.canonical_state(sd0, requires_grad=True)
-    r32 = deeplab_ref.deeplab_forward(o32, x, training=True, masks=masks)
+    r32 = deeplab_ref.deeplab_forward(o32, x, training=True, masks=masks, output_stride=output_stride)
     total(r32, torch.float32, "cpu").backward()
     o64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.clone())
            for k, v in deeplab_ref.canonical_state(sd0, requires_grad=True).items()}
-    r64 = deeplab_ref.deeplab_forward(o64, x.double(), training=True, masks=masks)
+    r64 = deeplab_ref.deeplab_forward(o64, x.double(), training=True, masks=masks, output_stride=output_stride)
     total(r64, torch.float64, "cpu").backward()
     m.to(dev)
     m.set_dropout_masks(masks)

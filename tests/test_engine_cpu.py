@@ -176,3 +176,19 @@ def test_input_size_must_be_a_multiple_of_16():
         m(torch.randn(2, 3, 72, 64))
     with pytest.raises(ValueError, match=r"\[N, 3, H, W\]"):
         m(torch.randn(2, 1, 64, 64))
+
+
+def test_output_stride_8_matches_oracle():
+    """--out-stride 8 (train_use_fix_initial.py:86-90): the last two stages trade stride for dilation (mobilenet.py:93-101),
+    the ASPP rates double (aspp.py:43-48)."""
+    torch.manual_seed(11)
+    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=8)
+    m._engine_override = GeneratorEngine(SpecKernels(), output_stride=8)
+    m.eval()
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        mine = m(x)
+        ref = deeplab_ref.deeplab_forward(deeplab_ref.canonical_state(m.state_dict()), x, training=False, output_stride=8)
+    for n, a, b in zip(NAMES, mine, ref):
+        assert a.shape == b.shape, n
+        assert _rel(a, b) < 2e-4, (n, _rel(a, b))

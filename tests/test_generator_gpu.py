@@ -192,3 +192,13 @@ def test_full_size_backward_agrees_with_forward_differences():
     an = gnorm
     assert abs(res[2.5e-4] - an) < 0.02 * an, (res, an)
     assert abs(res[2.5e-4] - an) <= abs(res[1e-3] - an) + 0.005 * an, (res, an)
+
+
+def test_output_stride_8_forward_backward():
+    """--out-stride 8: dilated last stages (dilation 2 and 4 depthwise convs, ASPP rates 12/24/36)."""
+    fwd, grads, stats, _ = model_cases.train_parity(DEV, B=2, S=64, output_stride=8)
+    assert max(fwd.values()) < 1e-3, fwd
+    assert stats < 1e-3
+    bad, gmean = model_cases.grads_ok(grads)
+    assert not bad, list(bad.items())[:10]
+    assert gmean < 4.0, gmean

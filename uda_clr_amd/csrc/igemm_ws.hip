@@ -626,8 +626,8 @@ static int launch_wg(WgradKArgs& k, int S, hipStream_t st) {
 
 int launch_wgrad_ws(WgradKArgs& k, int S, hipStream_t st) {
     const int64_t lim = (int64_t)1 << 31, P = (int64_t)k.src.N * k.src.H * k.src.W;
-    UDA_REQUIRE((P + 64) * k.src.ldx < lim && (P + 64) * k.lddy < lim && (P + 64) * (k.src.mask ? k.src.ldm : 1) < lim,
-                "uda_conv_wgrad: operand too large for the 32-bit element offsets of the wide-tile kernel");
+    UDA_REQUIRE((P + 64) * k.src.ldx < lim / 4 && (P + 64) * k.lddy < lim / 4 && (P + 64) * (k.src.mask ? k.src.ldm : 1) < lim,
+                "uda_conv_wgrad: operand too large for the 32-bit byte offsets of the wide-tile kernel (P * ld must stay below 2^29 elements)");
     const int xf = k.src.mask ? 2 : ((k.src.scale || k.src.act != ACT_NONE) ? 1 : 0);
     if (k.ksize >= 2) return xf == 2 ? launch_wg<3, 2>(k, S, st) : xf == 1 ? launch_wg<3, 1>(k, S, st) : launch_wg<3, 0>(k, S, st);
     return xf == 2 ? launch_wg<1, 2>(k, S, st) : xf == 1 ? launch_wg<1, 1>(k, S, st) : launch_wg<1, 0>(k, S, st);

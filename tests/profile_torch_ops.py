@@ -1,3 +1,7 @@
+"""Developer aid: which aten ops (stock torch glue around the HIP kernels) cost device time in a bench.py step.
+
+    python tests/profile_torch_ops.py prototype_full|source_only        # on the GPU box
+"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 sys.argv = ["bench.py", "--workload", sys.argv[1], "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]

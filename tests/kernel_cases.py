@@ -731,3 +731,11 @@ def case_relayout_s2d(O, C, seed=21):
 
 CASES += [("relayout s2d 64<-2", case_relayout_s2d(64, 2)), ("relayout s2d 128<-64", case_relayout_s2d(128, 64)),
           ("relayout s2d 1<-512", case_relayout_s2d(1, 512))]
+
+# 256 x 256 weight-gradient tiles (Cout >= 192, J >= 256, >= 4096 pixel chunks = 131072 pixels)
+CASES += [
+    ("wgrad3x3 32->256 P=131072 (256x256 tiles)", case_wgrad(2, 256, 256, 32, 256, 3, 1, lazy=False)),
+    ("wgrad3x3 40->200 P=131325 mask (256x256 tiles, ragged)", case_wgrad(1, 255, 515, 40, 200, 3, 2, mask=True)),
+    ("wgrad1x1 300->320 P=131072 lazy (256x256 tiles)", case_wgrad(2, 256, 256, 300, 320, 1, 1)),
+    ("wgrad2x2 o0 64->256 P=131841 (256x256 tiles)", case_wgrad(1, 363, 363, 64, 256, 2, 1, lazy=False)),
+]

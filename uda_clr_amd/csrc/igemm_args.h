@@ -33,4 +33,4 @@ struct WgradKArgs {
 #define WG_BKP 32
 
 int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st);          // 128 x {128,256} tiles
-int launch_wgrad_ws(WgradKArgs& k, int S, hipStream_t st);            // 128 x 128 tiles
+int launch_wgrad_ws(WgradKArgs& k, int S, bool big, hipStream_t st);  // 128 x 128 or 256 x 256 tiles

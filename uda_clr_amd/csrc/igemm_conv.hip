@@ -619,14 +619,16 @@ static WgradPlan wgrad_plan(int64_t P, int Cout, int Cin, int ksize) {
     const int Kc = ((Cin + 3) / 4) * 4, J = ksize * ksize * Kc;
     const int cm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     const int cn = J <= 32 ? 32 : (J <= 64 ? 64 : 128);
-    if (cm == 128 && cn == 32) { p.bm = 128; p.bn = 32; }
+    const bool big = Cout >= 192 && J >= 256 && uda_cdiv(P, WG_BKP) >= 4096;      // (measured: a loss below ~100k pixels)
+    if (big) { p.bm = 256; p.bn = 256; }
+    else if (cm == 128 && cn == 32) { p.bm = 128; p.bn = 32; }
     else if (cm == 32 && cn == 128) { p.bm = 32; p.bn = 128; }
     else if (cm <= 64 && cn <= 64) { p.bm = 64; p.bn = 64; }
     else { p.bm = 128; p.bn = 128; }
     p.nCot = uda_cdiv(Cout, p.bm);
     p.nJt = uda_cdiv(J, p.bn);
-    p.nchunks = uda_cdiv(P, (p.bm == 128 && p.bn == 128) ? WG_BKP : WGN_BKP);
-    int S = 1024 / (p.nCot * p.nJt);
+    p.nchunks = uda_cdiv(P, ((p.bm == 128 && p.bn == 128) || p.bm == 256) ? WG_BKP : WGN_BKP);
+    int S = (p.bm == 256 ? 512 : 1024) / (p.nCot * p.nJt);      // 256 x 256 tiles: one workgroup per CU, two rounds
     if (S > p.nchunks / 4) S = p.nchunks / 4;
     if (S < 1) S = 1;
     if (S > 256) S = 256;
@@ -669,7 +671,8 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     k.chunks_per_split = p.cps;
     k.nchunks = p.nchunks;
     dim3 grid(p.nCot * p.nJt, p.S);
-    if (p.bm == 128 && p.bn == 128) { if (int e = launch_wgrad_ws(k, p.S, st)) return e; }
+    if (p.bm == 256) { if (int e = launch_wgrad_ws(k, p.S, true, st)) return e; }
+    else if (p.bm == 128 && p.bn == 128) { if (int e = launch_wgrad_ws(k, p.S, false, st)) return e; }
     else if (p.bm == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, k);
     else if (p.bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 4, 1>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 1, 4>), grid, dim3(256), 0, st, k);

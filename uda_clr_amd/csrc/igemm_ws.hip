@@ -412,15 +412,18 @@ int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
 }
 
 // ==========================================================================================
-// Weight gradient, 128 (co) x 128 (j) tiles, same two-role structure.  Operand tiles are [pixel][row].
-template <int KS, int XF>
-__global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+// Weight gradient, same two-role structure.  Operand tiles are [pixel][row].  BIG = false: 128 (co) x 128 (j) tiles,
+// 4 math waves of 64 x 64; BIG = true: 256 x 256 tiles, 8 math waves of 64 x 128 (half the staging per MFMA, one
+// ds_read_b64 + one ds_read_b128 per 8 MFMAs), taken for the large layers (Cout >= 192, J >= 256, many pixel chunks).
+template <int KS, int XF, bool BIG>
+__global__ __launch_bounds__(BIG ? 768 : 512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
+    constexpr int BM = BIG ? 256 : 128, BN = BM, TM = 2, TN = BIG ? 4 : 2, MW = BIG ? 8 : 4;
+    constexpr int RV = BM / 4, RP = 256 / RV, NP = WG_BKP / RP;     // float4 per staged row, pixel rows per pass, passes
     constexpr int TILE = WG_BKP * (BM + BN);
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= MW;
     const int cot = blockIdx.x / a.nJt, jt = blockIdx.x % a.nJt;
     const int split = blockIdx.y;
     const int H = a.src.H, W = a.src.W, C = a.src.C;
@@ -428,9 +431,9 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     const int c0 = split * a.chunks_per_split;
     const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
 
-    // loader mapping: 32 float4 per staged row, 8 pixel rows per pass, 4 passes
-    const int lt = tid & 255;
-    const int cv = (lt & 31) * 4, pr = lt >> 5;
+    // loader mapping: RV float4 per staged row, RP pixel rows per pass, NP passes
+    const int lt = (tid - MW * 64) & 255;
+    const int cv = (lt % RV) * 4, pr = lt / RV;
     const int co = cot * BM + cv;
     const int j0 = jt * BN + cv;
     const bool jok = j0 < a.Jtot;
@@ -450,15 +453,15 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     const int act = a.src.act;
     const float ms = a.src.mask_scale;
     const bool ctail = (C & 3) != 0, cotail = (a.Cout & 3) != 0;
-    float4 areg[4], breg[4];
-    uint32_t bmask[4];
+    float4 areg[NP], breg[NP];
+    uint32_t bmask[NP];
     unsigned bok = 0;
     // per staged pixel row: pixel index and (h, w), advanced by 32 pixels per chunk without divisions
-    int pp[4], hh0[4], ww0[4];
+    int pp[NP], hh0[NP], ww0[NP];
     if (loader) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t p = (int64_t)c0 * WG_BKP + pr + i * 8;
+        for (int i = 0; i < NP; ++i) {
+            const int64_t p = (int64_t)c0 * WG_BKP + pr + i * RP;
             const int q = (int)(p < P ? p : 0);
             pp[i] = (int)p;
             ww0[i] = q % W;
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     auto issue = [&]() {
         bok = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const bool pin = pp[i] < (int)P;
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                 yres, (pin && co < a.Cout) ? (pp[i] * lddy + co) * 4 : OOB, 0, 0));
@@ -504,14 +507,14 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
         float* As = buf;
         float* Bs = buf + WG_BKP * BM;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
             if (cotail) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (co + j >= a.Cout) v[j] = 0.f;
             }
-            uda_st4(&As[(pr + i * 8) * BM + cv], make_float4(v[0], v[1], v[2], v[3]));
+            uda_st4(&As[(pr + i * RP) * BM + cv], make_float4(v[0], v[1], v[2], v[3]));
         }
         // prologue on packed pairs with a one-instruction clamp, as in the forward kernel's loader
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
         const f32x2 sh01 = {xf.sh[0], xf.sh[1]}, sh23 = {xf.sh[2], xf.sh[3]};
         const float alo = act == ACT_NONE ? -INFINITY : 0.f, ahi = act == ACT_RELU6 ? 6.f : INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             float v[4] = {breg[i].x, breg[i].y, breg[i].z, breg[i].w};
             const bool ok = (bok >> i) & 1u;
             if (XF >= 1) {
@@ -545,14 +548,14 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
                 for (int j = 0; j < 4; ++j)
                     if ((ci + j) >= C) v[j] = 0.f;
             }
-            uda_st4(&Bs[(pr + i * 8) * BN + cv], make_float4(v[0], v[1], v[2], v[3]));
+            uda_st4(&Bs[(pr + i * RP) * BN + cv], make_float4(v[0], v[1], v[2], v[3]));
         }
     };
 
-    const int wm = (wave & 3) >> 1, wn = wave & 1;
-    // MFMA row/column slot r of a wave owns tile rows 2r and 2r+1 (blocks i = 0, 1): the two values a lane needs per
-    // k-step are adjacent in LDS and come with ONE ds_read_b64 per operand (was two ds_read_b32)
-    const int acol = wm * 64 + 2 * (lane & 31), bcol = wn * 64 + 2 * (lane & 31), kh = lane >> 5;
+    const int wm = BIG ? (wave >> 1) & 3 : (wave & 3) >> 1, wn = wave & 1;
+    // MFMA row slot r of a wave owns tile rows 2r and 2r+1 (blocks i = 0, 1), column slot r owns columns TN*r .. TN*r+TN-1:
+    // the values a lane needs per k-step are adjacent in LDS and come with ONE ds_read_b64 / ds_read_b128 per operand
+    const int acol = wm * 64 + 2 * (lane & 31), bcol = wn * (32 * TN) + TN * (lane & 31), kh = lane >> 5;
     const int n = c1 - c0;
     if (loader) {
         if (n > 0) {
@@ -582,10 +585,16 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
             const float* Bs = As + WG_BKP * BM;
 #pragma unroll
             for (int kk = 0; kk < WG_BKP / 2; ++kk) {
-                static_assert(TM == 2 && TN == 2, "paired-row fragment reads");
                 const float2 a2 = *reinterpret_cast<const float2*>(&As[(2 * kk + kh) * BM + acol]);
-                const float2 b2 = *reinterpret_cast<const float2*>(&Bs[(2 * kk + kh) * BN + bcol]);
-                const float af[TM] = {a2.x, a2.y}, bf[TN] = {b2.x, b2.y};
+                const float af[TM] = {a2.x, a2.y};
+                float bf[TN];
+                if constexpr (BIG) {
+                    const float4 b4 = uda_ld4(&Bs[(2 * kk + kh) * BN + bcol]);
+                    bf[0] = b4.x; bf[1] = b4.y; bf[2] = b4.z; bf[3] = b4.w;
+                } else {
+                    const float2 b2 = *reinterpret_cast<const float2*>(&Bs[(2 * kk + kh) * BN + bcol]);
+                    bf[0] = b2.x; bf[1] = b2.y;
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = jt * BN + wn * 64 + 2 * (lane & 31) + j;
+                const int col = jt * BN + wn * (32 * TN) + TN * (lane & 31) + j;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = cot * BM + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + i;
@@ -609,26 +618,31 @@ __global__ __launch_bounds__(512) void igemm_wgrad_ws_kernel(WgradKArgs a) {
     }
 }
 
-template <int KS, int XF>
+template <int KS, int XF, bool BIG>
 static int launch_wg(WgradKArgs& k, int S, hipStream_t st) {
-    constexpr size_t lds = 2 * WG_BKP * 256 * sizeof(float);
+    constexpr size_t lds = 2 * WG_BKP * (BIG ? 512 : 256) * sizeof(float);
     static bool configured = false;
-    auto fn = igemm_wgrad_ws_kernel<KS, XF>;
+    auto fn = igemm_wgrad_ws_kernel<KS, XF, BIG>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return uda_set_error("igemm_wgrad_ws: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         configured = true;
     }
-    hipLaunchKernelGGL(fn, dim3(k.nCot * k.nJt, S), dim3(512), lds, st, k);
+    hipLaunchKernelGGL(fn, dim3(k.nCot * k.nJt, S), dim3(BIG ? 768 : 512), lds, st, k);
     UDA_LAUNCH_CHECK("igemm_wgrad_ws");
     return 0;
 }
 
-int launch_wgrad_ws(WgradKArgs& k, int S, hipStream_t st) {
+template <int KS, bool BIG>
+static int launch_wg_xf(WgradKArgs& k, int S, int xf, hipStream_t st) {
+    return xf == 2 ? launch_wg<KS, 2, BIG>(k, S, st) : xf == 1 ? launch_wg<KS, 1, BIG>(k, S, st) : launch_wg<KS, 0, BIG>(k, S, st);
+}
+
+int launch_wgrad_ws(WgradKArgs& k, int S, bool big, hipStream_t st) {
     const int64_t lim = (int64_t)1 << 31, P = (int64_t)k.src.N * k.src.H * k.src.W;
     UDA_REQUIRE((P + 64) * k.src.ldx < lim / 4 && (P + 64) * k.lddy < lim / 4 && (P + 64) * (k.src.mask ? k.src.ldm : 1) < lim,
                 "uda_conv_wgrad: operand too large for the 32-bit byte offsets of the wide-tile kernel (P * ld must stay below 2^29 elements)");
     const int xf = k.src.mask ? 2 : ((k.src.scale || k.src.act != ACT_NONE) ? 1 : 0);
-    if (k.ksize >= 2) return xf == 2 ? launch_wg<3, 2>(k, S, st) : xf == 1 ? launch_wg<3, 1>(k, S, st) : launch_wg<3, 0>(k, S, st);
-    return xf == 2 ? launch_wg<1, 2>(k, S, st) : xf == 1 ? launch_wg<1, 1>(k, S, st) : launch_wg<1, 0>(k, S, st);
+    if (k.ksize >= 2) return big ? launch_wg_xf<3, true>(k, S, xf, st) : launch_wg_xf<3, false>(k, S, xf, st);
+    return big ? launch_wg_xf<1, true>(k, S, xf, st) : launch_wg_xf<1, false>(k, S, xf, st);
 }

@@ -364,6 +364,8 @@ CASES = [
     ("conv1x1 1280->256 relu", case_conv(2, 8, 8, 1280, 256, 1, 1)),
     ("conv1x1 305->2 bias mask (C%4!=0)", case_conv(2, 16, 16, 305, 2, 1, 1, mask=True, bias=True, stats=False)),
     ("conv1x1 256->1 bias mask", case_conv(2, 16, 16, 256, 1, 1, 1, mask=True, bias=True, stats=False)),
+    ("conv1x1 100->2 addend, ragged P (heads kernel, raw operand)", case_conv(2, 17, 13, 100, 2, 1, 1, lazy=False, addend=True, stats=False)),
+    ("conv1x1 68->1 lazy, P < 128 (heads kernel)", case_conv(1, 9, 7, 68, 1, 1, 1, bias=True, stats=False)),
     ("conv1x1 320->256 P=N (gap branch)", case_conv(4, 1, 1, 320, 256, 1, 1, lazy=False)),
     ("conv1x1 24->48 addend", case_conv(2, 16, 16, 24, 48, 1, 1, addend=True, stats=False)),
     # 3x3 convs

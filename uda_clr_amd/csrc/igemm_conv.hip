@@ -353,6 +353,67 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvKArgs a) {
     }
 }
 
+// 1x1 convs with one or two outputs on a lazily transformed operand (the segmentation / boundary heads, decoder.py:32,41:
+// BN + ReLU + dropout on 305 / 256 channels -> 2 / 1 logits): a per-pixel dot product, 16 lanes per pixel, 16-byte loads
+// along the channels, per-channel coefficients and weights in LDS.  HBM-bound (the operand and its mask are read once),
+// where the 128 x 32 MFMA tile spends 32 columns on 1-2 useful ones.
+template <int NO>
+__global__ __launch_bounds__(256) void conv_heads_kernel(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];       // [2 + NO][Kc]: scale, shift, w[0..NO)
+    const int Kc = a.Kc, C = a.src.C;
+    for (int e = threadIdx.x; e < Kc; e += 256) {
+        const bool in = e < C;
+        hsm[e] = (in && a.src.scale) ? a.src.scale[e] : 1.f;
+        hsm[Kc + e] = (in && a.src.shift) ? a.src.shift[e] : 0.f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) hsm[(2 + o) * Kc + e] = in ? a.w[(int64_t)o * a.Ktot + e] : 0.f;
+    }
+    __syncthreads();
+    const int l16 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int64_t P = (int64_t)a.src.N * a.src.H * a.src.W;
+    const float alo = a.src.act == ACT_NONE ? -INFINITY : 0.f, ahi = a.src.act == ACT_RELU6 ? 6.f : INFINITY;
+    const float ms = a.src.mask_scale;
+    const int G = Kc >> 2;
+    for (int it = 0; it < 8; ++it) {
+        const int64_t p = (int64_t)blockIdx.x * 128 + it * 16 + pl;
+        float acc[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+        if (p < P) {
+            const float* xr = a.src.x + p * a.src.ldx;
+            for (int g = l16; g < G; g += 16) {
+                const int c = g * 4;
+                const float4 xv = uda_ld4(xr + c), sc = uda_ld4(&hsm[c]), sh = uda_ld4(&hsm[Kc + c]);
+                float u[4] = {__builtin_amdgcn_fmed3f(xv.x * sc.x + sh.x, alo, ahi), __builtin_amdgcn_fmed3f(xv.y * sc.y + sh.y, alo, ahi),
+                              __builtin_amdgcn_fmed3f(xv.z * sc.z + sh.z, alo, ahi), __builtin_amdgcn_fmed3f(xv.w * sc.w + sh.w, alo, ahi)};
+                if (a.src.mask) {
+                    const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
+                    u[0] *= (float)(mk & 0xffu) * ms; u[1] *= (float)((mk >> 8) & 0xffu) * ms;
+                    u[2] *= (float)((mk >> 16) & 0xffu) * ms; u[3] *= (float)(mk >> 24) * ms;
+                }
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const float4 wv = uda_ld4(&hsm[(2 + o) * Kc + c]);      // zero beyond C: garbage lanes of the last granule drop out
+                    acc[o] += u[0] * wv.x + u[1] * wv.y + u[2] * wv.z + u[3] * wv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1) acc[o] += __shfl_xor(acc[o], d);
+        }
+        if (l16 == 0 && p < P) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                float v = acc[o] + (a.bias ? a.bias[o] : 0.f);
+                if (a.addend) v += a.addend[p * a.ld_add + o];
+                a.y[p * a.ldy + o] = v;
+            }
+        }
+    }
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -396,6 +457,13 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     if (a->Cout == 1 && !a->src.scale && !a->src.mask && a->src.act == ACT_NONE && !a->stats && k.Ktot >= 1024) {
         hipLaunchKernelGGL(conv_cout1_kernel, dim3(uda_cdiv(P, 4)), dim3(256), 0, st, k);
         UDA_LAUNCH_CHECK("conv_cout1");
+        return 0;
+    }
+    if (a->Cout <= 2 && a->ksize == 1 && !a->stats && k.Kc >= 64 && k.Kc <= 2048) {
+        const size_t lds = (size_t)(2 + a->Cout) * k.Kc * sizeof(float);
+        if (a->Cout == 1) hipLaunchKernelGGL(conv_heads_kernel<1>, dim3(uda_cdiv(P, 128)), dim3(256), lds, st, k);
+        else hipLaunchKernelGGL(conv_heads_kernel<2>, dim3(uda_cdiv(P, 128)), dim3(256), lds, st, k);
+        UDA_LAUNCH_CHECK("conv_heads");
         return 0;
     }
     if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);

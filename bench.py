@@ -95,7 +95,7 @@ def measured_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS configuration
     (profiles/r01_igemm_conv_ws_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, see profiles/pmc_traffic.py), in GB;
     None for any other configuration (counters cannot be collected from inside the timed run)."""
-    if (args.workload, args.backbone, args.batch, args.size) != ("prototype_full", "mobilenet", 16, 512):
+    if (args.workload, args.backbone, args.batch, args.size, args.use_tn) != ("prototype_full", "mobilenet", 16, 512, False):
         return None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_conv_ws_traffic.json")
     if not os.path.exists(path):
@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--workload", choices=("prototype_full", "source_only"), default="prototype_full")
     ap.add_argument("--backbone", choices=("mobilenet", "resnet"), default="mobilenet",
                     help="resnet = the ResNet-101 variant of BASELINE.json configs[4] (quoted at --batch 8)")
+    ap.add_argument("--use-tn", action="store_true",
+                    help="the --use_TN model of train_use_fix_initial.py:98-100,180-181 (TransNorm layers; not a BASELINE.json config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -180,7 +182,7 @@ def main():
     from uda_clr_amd.train_process import Trainer_baseline, Trainer_prototype_full
     load_library()
     torch.manual_seed(1337)
-    model = DeepLab(num_classes=2, backbone=args.backbone, output_stride=16, sync_bn=True, freeze_bn=False,
+    model = DeepLab(num_classes=2, backbone=args.backbone, output_stride=16, sync_bn=not args.use_tn, freeze_bn=False,
                     method=args.workload).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.99))
     img, tmap, tbd = synth_batch(args.batch, args.size, 1337 + rank, dev)
@@ -253,6 +255,8 @@ def main():
         if args.backbone == "resnet":
             desc = desc.replace("DeepLabV3+/MobileNetV2", "DeepLabV3+/ResNet-101").replace("configs[1]", "configs[4] shape, 1 GPU").replace(
                 "configs[2]", "configs[4] shape, 1 GPU")
+        if args.use_tn:
+            desc = desc.replace("DeepLabV3+/MobileNetV2", "DeepLabV3+/MobileNetV2 with TransNorm (--use_TN: per-domain-half launches)")
         line = {
             "metric": "training images/sec (512x512, src+tgt) at 1/2/4/8 MI355X; val Dice vs ref",
             "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -274,7 +278,7 @@ def main():
                 gbs = line["value"] / world * 1.39
                 line["step_roofline"].update(algorithmic_gb_per_image=1.39, achieved_gb_s_per_gpu=round(gbs, 1),
                                              hbm_frac=round(gbs / 8000.0, 4))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.use_tn:
             line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size, args.backbone)
         print(json.dumps(line), flush=True)
     if dist is not None:

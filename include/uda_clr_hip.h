@@ -166,6 +166,18 @@ int uda_bn_running_replay(const float* mean, const float* invstd, int C, double 
 int uda_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, int C, float eps, float* scale, float* shift,
                        void* stream);
+/* TransNorm, the --use_TN normalisation (networks/sync_batchnorm/batchnorm.py:436-520, training branch :445-495,
+ * eval branch :497-520).  Training: a batch is normalised per domain half (first N/2 images "source", the rest
+ * "target"): the caller runs uda_bn_finalize once per half (its own statistics accumulator, count and running
+ * buffers), then uda_tn_gain turns the two accumulators into gain[c] = 1 + C p_c / sum(p),
+ * p_c = 1 / (1 + |mu_s/sqrt(var_s+eps) - mu_t/sqrt(var_t+eps)|) (unbiased variances, :474-483) and multiplies
+ * both halves' scale/shift by it in place (the reference's z * (1 + alpha.detach()), :495).  Eval: the target
+ * running statistics normalise and the gain comes from the two pairs of running statistics (:501-520). */
+int uda_tn_gain(const double* stats0, const double* stats1, int C, double count0, double count1, float eps,
+                float* scale0, float* shift0, float* scale1, float* shift1, float* gain, void* stream);
+int uda_tn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean_source,
+                       const float* running_var_source, const float* running_mean_target,
+                       const float* running_var_target, int C, float eps, float* scale, float* shift, void* stream);
 /* out = transform(src) + residual */
 int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t ldr, float* out, int64_t ldo,
                  void* stream);

@@ -61,8 +61,41 @@ class _Ctx:
     def __init__(self, sd, training, masks, record):
         self.sd, self.training, self.masks, self.record = sd, training, masks, record
 
+    def transnorm(self, x, prefix):
+        """TransNorm (``--use_TN``; networks/sync_batchnorm/batchnorm.py:436-520).  Training: the first
+        N//2 images of WHATEVER batch arrives are the "source" half, the rest the "target" half; each half is
+        batch-normalised with its own statistics (and updates its own running buffers), then both are scaled
+        per channel by 1 + alpha, alpha = C * p / sum(p), p = 1 / (1 + |mu_s/sqrt(var_s+eps) - mu_t/sqrt(var_t+eps)|)
+        with the UNBIASED variances of the two halves; alpha carries no gradient.  Eval: target running
+        statistics normalise, alpha comes from the two pairs of running statistics."""
+        sd = self.sd
+        w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+        rms, rvs = sd[prefix + ".running_mean_source"], sd[prefix + ".running_var_source"]
+        rmt, rvt = sd[prefix + ".running_mean_target"], sd[prefix + ".running_var_target"]
+        C = x.shape[1]
+        if self.training:
+            sd[prefix + ".num_batches_tracked"] += 1
+            n0 = x.shape[0] // 2
+            halves = (x[:n0], x[n0:])
+            z = torch.cat([F.batch_norm(h, rm, rv, w, b, True, BN_MOMENTUM, BN_EPS)
+                           for h, rm, rv in zip(halves, (rms, rmt), (rvs, rvt))], 0)
+            # [pixels, C] rows reduced along dim 0: the reference's reduction layout, so fp32 sums round identically
+            flat = [h.permute(0, 2, 3, 1).reshape(-1, C) for h in halves]
+            ratio = [f.mean(0) / torch.sqrt(f.var(0) + BN_EPS) for f in flat]
+        else:
+            z = F.batch_norm(x, rmt, rvt, w, b, False, BN_MOMENTUM, BN_EPS)
+            ratio = [rms / torch.sqrt(rvs + BN_EPS), rmt / torch.sqrt(rvt + BN_EPS)]
+        prob = 1.0 / (1.0 + (ratio[0] - ratio[1]).abs())
+        total = prob[0]
+        for v in prob[1:]:               # the reference adds the C terms one by one (Python ``sum``): same fp32 rounding order
+            total = total + v
+        alpha = (C * prob / total).detach()
+        return z * (1.0 + alpha.view(1, C, 1, 1))
+
     def bn(self, x, prefix):
         sd = self.sd
+        if (prefix + ".running_mean_source") in sd:
+            return self.transnorm(x, prefix)
         if self.training and (prefix + ".num_batches_tracked") in sd:
             sd[prefix + ".num_batches_tracked"] += 1
         return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
@@ -227,6 +260,10 @@ def draw_masks(batch, height, width, generator=None):
     return out
 
 
+def _is_running_stat(k):
+    return k.rsplit(".", 1)[-1].startswith(("running_mean", "running_var"))     # incl. TransNorm's _source / _target
+
+
 def canonical_state(sd, requires_grad=False):
     """Drop the aliased low_level_/high_level_ keys (mobilenet.py:116-117, quirk Q10)
     and return float32 clones; parameters optionally ``requires_grad``."""
@@ -236,15 +273,14 @@ def canonical_state(sd, requires_grad=False):
             continue
         t = v.detach().clone()
         if requires_grad and t.is_floating_point() and not (
-                k.endswith("running_mean") or k.endswith("running_var")):
+                _is_running_stat(k)):
             t.requires_grad_(True)
         out[k] = t
     return out
 
 
 def parameter_keys(sd):
-    return [k for k, v in sd.items() if v.is_floating_point()
-            and not k.endswith("running_mean") and not k.endswith("running_var")]
+    return [k for k, v in sd.items() if v.is_floating_point() and not _is_running_stat(k)]
 
 
 class OracleDeepLab(torch.nn.Module):

@@ -12,6 +12,7 @@ inputs and stores inputs' seeds + expected outputs as small data files:
 
   manifest.json          state-dict keys/shapes of DeepLab(mobilenet) + seeded-init checksums
   manifest_resnet.json   the same for DeepLab(resnet) (ResNet-101, pretrained fetch patched out)
+  manifest_tn.json, forward_tn_64.npz   the --use_TN model (DeepLab(sync_bn=False): TransNorm layers), B = 4
   forward_*.npz          7-tuple outputs (checksums + strided samples), BN running stats,
                          seg loss and per-parameter gradient norms (eval / train, 64^2 / 512^2)
   proto.npz              gen_prototype / gen_prototype_retrify inputs (by seed) and outputs
@@ -81,10 +82,11 @@ def install_reference():
     resnet.ResNet._load_pretrained_model = lambda self: None
 
 
-def ref_model(seed=1337, backbone="mobilenet"):
+def ref_model(seed=1337, backbone="mobilenet", sync_bn=True):
+    """sync_bn=False is the --use_TN model of train_use_fix_initial.py:180-181 (TransNorm layers)."""
     from networks.deeplabv3 import DeepLab
     torch.manual_seed(seed)
-    return DeepLab(num_classes=2, backbone=backbone, output_stride=16, sync_bn=True,
+    return DeepLab(num_classes=2, backbone=backbone, output_stride=16, sync_bn=sync_bn,
                    freeze_bn=False, method="prototype_full")
 
 
@@ -132,8 +134,8 @@ def check(name, a, b, tol=1e-5):
 
 
 # ----------------------------------------------------------------------------- fixtures
-def make_manifest(backbone="mobilenet", fname="manifest.json"):
-    m = ref_model(backbone=backbone)
+def make_manifest(backbone="mobilenet", fname="manifest.json", sync_bn=True):
+    m = ref_model(backbone=backbone, sync_bn=sync_bn)
     sd = m.state_dict()
     entries = [{"key": k, "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
                 "sum": float(v.double().sum())} for k, v in sd.items()]
@@ -196,7 +198,7 @@ def make_forward(m, B, S, tag):
     out["train.grad_norm"] = np.array(gn)
     out["train.grad_keys"] = np.array(keys)
     rs = m.state_dict()
-    bn_keys = [k for k in rs if k.endswith("running_mean") or k.endswith("running_var")]
+    bn_keys = [k for k in rs if k.rsplit(".", 1)[-1].startswith(("running_mean", "running_var"))]
     bn_keys = [k for k in bn_keys if "_level_features" not in k]
     out["train.bn_keys"] = np.array(bn_keys)
     out["train.bn_sum"] = np.array([rs[k].double().sum().item() for k in bn_keys])
@@ -396,7 +398,13 @@ def make_trainer_proto(tmp):
 if __name__ == "__main__":
     import tempfile
     install_reference()
-    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn"]
+    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn", "tn"]
+    if "tn" in which:        # TransNorm variant (--use_TN): B = 4 so each domain half has 2 images
+        mt = make_manifest("mobilenet", "manifest_tn.json", sync_bn=False)
+        make_forward(mt, 4, 64, "tn_64")
+        del mt
+        if which == ["tn"]:
+            raise SystemExit(0)
     if "rn" in which:        # ResNet-101 variant (BASELINE.json configs[4]); pretrained fetch patched out (8c)
         mr = make_manifest("resnet", "manifest_resnet.json")
         make_forward(mr, 2, 128, "resnet_128")

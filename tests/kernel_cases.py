@@ -196,6 +196,34 @@ def case_stem(N, H, W, seed=4):
     return run
 
 
+def case_transnorm(C, n0=300, n1=500, seed=9):
+    """uda_tn_gain / uda_tn_eval_coeffs against their torch statement (batchnorm.py:474-520)."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        xs = [2.0 * torch.randn(n0, C, generator=g) + 0.5, 0.7 * torch.randn(n1, C, generator=g) - 0.2]
+        st = torch.zeros(2, 16, 2, C, dtype=torch.float64)
+        for h in (0, 1):
+            SPEC.colstats(xs[h], st[h])
+        st = st[:, torch.randperm(16, generator=g)]                  # any slot may hold the sums
+        gamma, beta = 0.5 + torch.rand(C, generator=g), torch.randn(C, generator=g)
+        cr = torch.randn(2, 2, C, generator=g)                        # [scale | shift][half][C], pre-filled as after bn_finalize
+        ch = cr.to(dev)
+        gr, gh = torch.empty(C), torch.empty(C, device=dev)
+        SPEC.tn_gain(st[0], st[1], float(n0), float(n1), 1e-5, cr[0, 0], cr[1, 0], cr[0, 1], cr[1, 1], gr)
+        sth = st.to(dev)
+        K.tn_gain(sth[0], sth[1], float(n0), float(n1), 1e-5, ch[0, 0], ch[1, 0], ch[0, 1], ch[1, 1], gh)
+        errs = [rel(gh, gr), rel(ch, cr)]
+        rms, rmt = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        rvs, rvt = 0.5 + torch.rand(C, generator=g), 0.5 + torch.rand(C, generator=g)
+        er, eh = torch.empty(2, C), torch.empty(2, C, device=dev)
+        SPEC.tn_eval_coeffs(gamma, beta, rms, rvs, rmt, rvt, 1e-5, er[0], er[1])
+        K.tn_eval_coeffs(gamma.to(dev), beta.to(dev), rms.to(dev), rvs.to(dev), rmt.to(dev), rvt.to(dev), 1e-5, eh[0], eh[1])
+        errs.append(rel(eh, er))
+        return max(errs), 2e-6
+    return run
+
+
 def case_bn(P, C, q1=False, mask=False, training=True, seed=5):
     def run(dev):
         g = gen(seed)
@@ -405,6 +433,8 @@ CASES = [
     ("bn C=96 q1", case_bn(1500, 96, q1=True)),
     ("bn C=256 mask", case_bn(700, 256, mask=True)),
     ("bn C=305 mask (C%4!=0)", case_bn(600, 305, mask=True)),
+    ("transnorm gain / eval coefficients C=305", case_transnorm(305)),
+    ("transnorm gain / eval coefficients C=1280 (> one pass of the workgroup)", case_transnorm(1280, 40, 24)),
     ("bn C=1024 (concat)", case_bn(300, 1024)),
     ("bn eval C=144", case_bn(500, 144, training=False)),
     ("bn C=256 P=4", case_bn(4, 256)),

@@ -295,6 +295,30 @@ class SpecKernels:
         scale.copy_(sc.float())
         shift.copy_((beta.double() - rmean.double() * sc).float())
 
+    def tn_gain(self, stats0, stats1, count0, count1, eps, scale0, shift0, scale1, shift1, gain):
+        """TransNorm gain 1 + alpha from the two halves' (sum, sumsq) accumulators (unbiased variances), folded into
+        both halves' BN coefficients (batchnorm.py:474-495)."""
+        ratio = []
+        for st, n in ((stats0, count0), (stats1, count1)):
+            t = st.sum(0)
+            m = t[0] / n
+            var = (t[1] / n - m * m).clamp_min(0.0) * (n / (n - 1.0))
+            ratio.append(m / torch.sqrt(var + eps))
+        prob = 1.0 / (1.0 + (ratio[0] - ratio[1]).abs())
+        g = (1.0 + prob.numel() * prob / prob.sum()).float()
+        gain.copy_(g)
+        for t in (scale0, shift0, scale1, shift1):
+            t.mul_(g)
+
+    def tn_eval_coeffs(self, gamma, beta, rmean_s, rvar_s, rmean_t, rvar_t, eps, scale, shift):
+        rs = rmean_s.double() / torch.sqrt(rvar_s.double() + eps)
+        rt = rmean_t.double() / torch.sqrt(rvar_t.double() + eps)
+        prob = 1.0 / (1.0 + (rs - rt).abs())
+        g = 1.0 + prob.numel() * prob / prob.sum()
+        sc = gamma.double() / torch.sqrt(rvar_t.double() + eps)
+        scale.copy_((sc * g).float())
+        shift.copy_(((beta.double() - rmean_t.double() * sc) * g).float())
+
     def bn_apply(self, src: Act, out, residual=None):
         u = transform(src)
         if residual is not None:

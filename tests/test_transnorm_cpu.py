@@ -1,0 +1,204 @@
+"""not-gpu: the --use_TN model (DeepLab(sync_bn=False), TransNorm layers).
+
+* the oracle's TransNorm restatement against the fixture written by the reference's own DeepLab(sync_bn=False)
+  (tests/golden/forward_tn_64.npz, manifest_tn.json; generator: tests/golden/make_golden.py tn);
+* the engine's per-domain-half execution (uda_clr_amd/domain_split.py), driven with the tests' torch statement of the
+  kernel entry points, against that oracle: eval / train forward, the hand-written backward, both pairs of running
+  statistics, odd batches (halves of N//2 and N - N//2 images)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import model_cases
+from kernel_spec import SpecKernels
+from make_golden_inputs import synth_targets
+from oracle import deeplab_ref, step_ref
+from uda_clr_amd.engine import GeneratorEngine
+from uda_clr_amd.networks.deeplabv3 import DeepLab
+from uda_clr_amd.networks.sync_batchnorm.batchnorm import BatchNorm2d as TransNorm2d
+
+NAMES = ("x1", "x2", "feature", "x_bu_feature", "x_feature", "x1_before", "x2_before")
+
+
+def _tn_model(seed=1337, perturb=True):
+    torch.manual_seed(seed)
+    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=False)
+    m._engine_override = GeneratorEngine(SpecKernels(), transnorm=True)
+    if perturb:
+        g = torch.Generator().manual_seed(5)
+        for k, v in m.state_dict().items():
+            leaf = k.rsplit(".", 1)[-1]
+            if leaf.startswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif leaf.startswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+        for mod in m.modules():
+            if isinstance(mod, TransNorm2d):
+                mod.weight.data.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+                mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    return m
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+
+
+def _sample(t, n=97):
+    f = t.detach().double().reshape(-1)
+    return f[torch.linspace(0, f.numel() - 1, n).long()].numpy()
+
+
+def test_state_dict_matches_reference_manifest(golden_dir):
+    man = json.load(open(os.path.join(golden_dir, "manifest_tn.json")))
+    torch.manual_seed(man["seed"])
+    sd = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=False).state_dict()
+    assert len(sd) == man["n_state_keys"] == 899
+    for e, (k, v) in zip(man["entries"], sd.items()):
+        assert e["key"] == k and e["shape"] == list(v.shape), (e["key"], k)
+        assert abs(float(v.double().sum()) - e["sum"]) <= 1e-6 * max(1.0, abs(e["sum"])), k
+
+
+def test_oracle_transnorm_against_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "forward_tn_64.npz"))
+    B, S = int(z["B"]), int(z["S"])
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    sd0 = _tn_model(perturb=False).state_dict()
+    with torch.no_grad():
+        out = deeplab_ref.deeplab_forward(deeplab_ref.canonical_state(sd0), x, training=False)
+    for n, t in zip(NAMES, out):
+        np.testing.assert_allclose(_sample(t), z["eval.%s.smp" % n], rtol=1e-5, atol=1e-6)
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    osd = deeplab_ref.canonical_state(sd0, requires_grad=True)
+    torch.manual_seed(int(z["dropout_seed"]))
+    out = deeplab_ref.deeplab_forward(osd, x, training=True)
+    loss = step_ref.seg_loss(out[0], out[1], tmap, tbd)
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-6
+    for n, t in zip(NAMES, out):
+        np.testing.assert_allclose(_sample(t), z["train.%s.smp" % n], rtol=2e-5, atol=2e-6)
+    gn = np.array([osd[k].grad.double().norm().item() for k in z["train.grad_keys"]])
+    np.testing.assert_allclose(gn, z["train.grad_norm"], rtol=1e-4)
+    bs = np.array([osd[k].double().sum().item() for k in z["train.bn_keys"]])
+    np.testing.assert_allclose(bs, z["train.bn_sum"], rtol=1e-5, atol=1e-6)
+    assert len(z["train.bn_keys"]) == 4 * 61           # source and target running statistics of all 61 layers
+
+
+def _calibrate_running_stats(m, x):
+    """Running statistics := the batch statistics of x's two halves (one oracle training forward with momentum 1), so the
+    eval network is a normalised one.  (With the initial buffers - mean 0, var 1 on both domains - nothing is normalised
+    and every layer doubles its input, alpha = 1: rounding differences then grow ~2.3x per block in ANY fp32 evaluation.)"""
+    sd = deeplab_ref.canonical_state(m.state_dict())
+    keep, deeplab_ref.BN_MOMENTUM = deeplab_ref.BN_MOMENTUM, 1.0
+    try:
+        with torch.no_grad():
+            deeplab_ref.deeplab_forward(sd, x, training=True)
+    finally:
+        deeplab_ref.BN_MOMENTUM = keep
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+
+
+def test_eval_forward_matches_oracle():
+    m = _tn_model()
+    g = torch.Generator().manual_seed(0)
+    xc = torch.randn(6, 3, 64, 64, generator=g)
+    xc[3:] = 0.6 * xc[3:] - 0.3                       # source and target statistics differ: alpha varies over channels
+    _calibrate_running_stats(m, xc)
+    m.eval()
+    x = torch.randn(3, 3, 64, 64, generator=g)
+    sd = deeplab_ref.canonical_state(m.state_dict())
+    with torch.no_grad():
+        mine = m(x)
+        ref = deeplab_ref.deeplab_forward(sd, x, training=False)
+        r64 = deeplab_ref.deeplab_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()},
+                                          x.double(), training=False)
+    for n, a, b, c in zip(NAMES, mine, ref, r64):
+        assert a.shape == b.shape, n
+        assert _rel(a, c) < 3.0 * _rel(b, c) + 2e-4, (n, _rel(a, c), _rel(b, c))
+
+
+@pytest.mark.parametrize("B", [8, 7])
+def test_train_forward_backward_matches_oracle(B):
+    """B = 8: halves of 4 images; B = 7: halves of 3 and 4.  (At B = 4 the image-pooling TransNorm normalises TWO values per
+    channel and half, and the fp32 oracle itself is 6e-2 from its fp64 run: too ill-conditioned to tell a bug from rounding.)"""
+    m = _tn_model().train()
+    S = 64
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    x[B // 2:] = 0.7 * x[B // 2:] + 0.2             # the two domain halves differ in statistics
+    tmap = (torch.rand(B, 2, S, S, generator=gen) > 0.5).float()
+    tbd = torch.rand(B, 1, S, S, generator=gen)
+    masks = deeplab_ref.draw_masks(B, S, S, gen)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    wf = [torch.randn(t, generator=gen) for t in (256, 304, 305, 2, 1)]
+
+    def total(outs):
+        x1, x2, feat, xbu, xf, x1b, x2b = outs
+        loss = step_ref.seg_loss(x1, x2, tmap.to(x1.dtype), tbd.to(x1.dtype))
+        for t, w in zip((feat, xbu, xf, x1b, x2b), wf):
+            loss = loss + 1e-2 * (t * w.to(t.dtype).view(1, -1, 1, 1)).pow(2).mean()
+        return loss
+
+    m.set_dropout_masks(masks)
+    outs = m(x)
+    loss = total(outs)
+    loss.backward()
+    osd = deeplab_ref.canonical_state(sd0, requires_grad=True)
+    ref = deeplab_ref.deeplab_forward(osd, x, training=True, masks=masks)
+    total(ref).backward()
+    o64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.clone())
+           for k, v in deeplab_ref.canonical_state(sd0, requires_grad=True).items()}
+    r64 = deeplab_ref.deeplab_forward(o64, x.double(), training=True, masks=masks)
+    total(r64).backward()
+    for n, a, b, c in zip(NAMES, outs, ref, r64):
+        assert _rel(a, c) < 3.0 * _rel(b, c) + 2e-4, (n, _rel(a, c), _rel(b, c))
+    live = m._flat_state()
+    grads = {}
+    for k in deeplab_ref.parameter_keys(osd):
+        g = live[k].grad
+        assert g is not None, k
+        grads[k] = (model_cases.l2rel(g, o64[k].grad), model_cases.l2rel(osd[k].grad, o64[k].grad))
+    bad, gmean = model_cases.grads_ok(grads)
+    assert not bad, list(bad.items())[:10]
+    assert gmean < 1.5, gmean
+    n_stats = 0
+    for k, v in osd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf.startswith(("running_mean", "running_var")):
+            assert _rel(live[k], o64[k]) < 3.0 * _rel(v, o64[k]) + 5e-4, k
+            assert not torch.equal(live[k], sd0[k]), k          # both domains' buffers moved
+            n_stats += 1
+        if leaf == "num_batches_tracked":
+            assert int(live[k]) == int(v) == 1
+    assert n_stats == 4 * 61
+
+
+def test_halves_too_small_raise_like_the_reference():
+    """A training batch of 2 or 3 images leaves one image in a domain half: the image-pooling BN of that half sees one value
+    per channel and F.batch_norm raises in the reference; so does the product."""
+    m = _tn_model().train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m(torch.randn(3, 3, 64, 64))
+    sd = deeplab_ref.canonical_state(m.state_dict())
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        deeplab_ref.deeplab_forward(sd, torch.randn(3, 3, 64, 64), training=True)
+
+
+def test_mc_passes_run_as_plain_forwards_under_transnorm():
+    """The repeated batch x.repeat(2) is split into its two copies of x (not into the halves of x), so the fast path of the
+    plain-BN model does not apply: logits equal the oracle's plain stochastic forwards on the repeated batch."""
+    B, S = 4, 64
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    m = _tn_model().train()
+    m.set_dropout_masks(deeplab_ref.draw_masks(B, S, S, gen))
+    m(x)
+    sd1 = deeplab_ref.canonical_state(m.state_dict())
+    mk = [deeplab_ref.draw_masks(2 * B, S, S, gen)]
+    preds = m.mc_dropout_logits(x, passes=1, reps=2, masks=mk)
+    with torch.no_grad():
+        ref = deeplab_ref.deeplab_forward(sd1, x.repeat(2, 1, 1, 1), training=True, masks=mk[0])[0]
+    assert _rel(preds, ref) < 2e-4

@@ -35,6 +35,7 @@ class BNRec:
     invstd: torch.Tensor           # [C] 1/sqrt(var+eps)
     count: float                   # elements per channel the statistics were taken over
     q1_border: bool = False        # statistics include the zero border of quirk Q1
+    gain: Optional[torch.Tensor] = None     # TransNorm: [C] factor 1 + alpha already folded into scale / shift
 
 
 @dataclass
@@ -50,6 +51,9 @@ class Act:
     mask_scale: float = 1.0
     bn: Optional[BNRec] = None
     meta: dict = field(default_factory=dict)
+    # TransNorm (--use_TN): images [0, split) and [split, N) were normalised separately; scale / shift (and the
+    # BNRec's mean / invstd, count = per-half counts) then hold one row per domain half, [2, C]
+    split: int = 0
 
     @property
     def C(self) -> int:
@@ -63,7 +67,21 @@ class Act:
     def lazy(self) -> bool:
         return self.scale is not None or self.mask is not None or self.act != ACT_NONE
 
+    def half(self, h: int) -> "Act":
+        """The domain half h of a split activation as an ordinary one (contiguous row range, its own coefficients)."""
+        assert self.split > 0
+        n0, n1 = (0, self.split) if h == 0 else (self.split, self.N)
+        ppi = self.P // self.N
+        rows = slice(n0 * ppi, n1 * ppi)
+        bn = None
+        if self.bn is not None:
+            bn = BNRec(self.bn.key, self.bn.mean[h], self.bn.invstd[h], self.bn.count[h], self.bn.q1_border, self.bn.gain)
+        return Act(self.x[rows], n1 - n0, self.H, self.W, None if self.scale is None else self.scale[h],
+                   None if self.shift is None else self.shift[h], self.act,
+                   None if self.mask is None else self.mask[rows], self.mask_scale, bn, self.meta)
+
     def check(self):
+        assert self.split == 0, "a domain-split activation reaches the kernels one half at a time (domain_split.DomainSplit)"
         assert self.x.dim() == 2 and self.x.stride(1) == 1, "activation must be a [P, C] row-major view"
         assert self.x.shape[0] == self.N * self.H * self.W
         assert self.x.stride(0) % 4 == 0 and self.x.stride(0) >= round4(self.C)

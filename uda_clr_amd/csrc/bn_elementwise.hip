@@ -114,6 +114,99 @@ extern "C" int uda_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 // ------------------------------------------------------------------------------------------
+// TransNorm (--use_TN; networks/sync_batchnorm/batchnorm.py:436-520).  One workgroup walks all channels:
+//   ratio_h[c] = mean_h / sqrt(var_h + eps)   (training: UNBIASED batch variance of domain half h; eval: running statistics)
+//   prob[c] = 1 / (1 + |ratio_0 - ratio_1|),  gain[c] = 1 + C * prob[c] / sum_c prob
+// and scales the per-half BN coefficients (already written by uda_bn_finalize / uda_bn_eval_coeffs) by gain[c].
+__device__ __forceinline__ double tn_block_sum(double v, double* red) {
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void tn_gain_kernel(const double* __restrict__ st0, const double* __restrict__ st1, int C,
+                                                      double n0, double n1, float eps, float* __restrict__ scale0,
+                                                      float* __restrict__ shift0, float* __restrict__ scale1,
+                                                      float* __restrict__ shift1, float* __restrict__ gain) {
+    __shared__ double red[4];
+    double part = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double* st = h ? st1 : st0;
+            const double n = h ? n1 : n0;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < UDA_STAT_SLOTS; ++k) {
+                s1 += st[(k * 2 + 0) * C + c];
+                s2 += st[(k * 2 + 1) * C + c];
+            }
+            const double m = s1 / n;
+            double var = s2 / n - m * m;
+            if (var < 0.0) var = 0.0;
+            r[h] = m / sqrt(var * (n / (n - 1.0)) + (double)eps);
+        }
+        const double prob = 1.0 / (1.0 + fabs(r[0] - r[1]));
+        gain[c] = (float)prob;            // parked; rescaled below
+        part += prob;
+    }
+    const double total = tn_block_sum(part, red);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = (float)(1.0 + (double)C * (double)gain[c] / total);
+        gain[c] = g;
+        scale0[c] *= g; shift0[c] *= g;
+        scale1[c] *= g; shift1[c] *= g;
+    }
+}
+
+extern "C" int uda_tn_gain(const double* stats0, const double* stats1, int C, double count0, double count1, float eps,
+                           float* scale0, float* shift0, float* scale1, float* shift1, float* gain, void* stream) {
+    UDA_REQUIRE(stats0 && stats1 && scale0 && shift0 && scale1 && shift1 && gain && C > 0, "uda_tn_gain: bad args");
+    UDA_REQUIRE(count0 > 1 && count1 > 1, "uda_tn_gain: each domain half needs more than 1 value per channel (got %g, %g)", count0, count1);
+    hipLaunchKernelGGL(tn_gain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats0, stats1, C, count0, count1, eps,
+                       scale0, shift0, scale1, shift1, gain);
+    UDA_LAUNCH_CHECK("tn_gain");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void tn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ rms, const float* __restrict__ rvs,
+                                                             const float* __restrict__ rmt, const float* __restrict__ rvt, int C,
+                                                             float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[4];
+    double part = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double rs = (double)rms[c] / sqrt((double)rvs[c] + (double)eps);
+        const double rt = (double)rmt[c] / sqrt((double)rvt[c] + (double)eps);
+        const double prob = 1.0 / (1.0 + fabs(rs - rt));
+        scale[c] = (float)prob;           // parked; replaced below
+        part += prob;
+    }
+    const double total = tn_block_sum(part, red);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double g = 1.0 + (double)C * (double)scale[c] / total;
+        const double sc = (double)gamma[c] / sqrt((double)rvt[c] + (double)eps);      // the TARGET statistics normalise
+        scale[c] = (float)(sc * g);
+        shift[c] = (float)(((double)beta[c] - (double)rmt[c] * sc) * g);
+    }
+}
+
+extern "C" int uda_tn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean_source,
+                                  const float* running_var_source, const float* running_mean_target,
+                                  const float* running_var_target, int C, float eps, float* scale, float* shift, void* stream) {
+    UDA_REQUIRE(gamma && beta && running_mean_source && running_var_source && running_mean_target && running_var_target &&
+                scale && shift && C > 0, "uda_tn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(tn_eval_coeffs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean_source,
+                       running_var_source, running_mean_target, running_var_target, C, eps, scale, shift);
+    UDA_LAUNCH_CHECK("tn_eval_coeffs");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 #define EW_ITER 16
 // Elementwise kernels: channel group cg = tid % G is FIXED per thread (its per-channel coefficients
 // live in registers), pixel lane pl = tid / G walks EW_ITER strips of PP = 256/G pixels; channels

@@ -1,0 +1,121 @@
+"""TransNorm execution (``--use_TN``): every launch that touches a per-domain normalisation runs once per domain half.
+
+The reference's TransNorm layer (networks/sync_batchnorm/batchnorm.py:445-495) normalises the first N//2 images of a
+training batch with their own batch statistics and the rest with theirs.  In this engine a normalisation is a
+pair of per-channel coefficients that the CONSUMER kernel applies while loading, and batch statistics are
+accumulated in the PRODUCER's epilogue, so "two statistics, two coefficient sets" maps onto the existing kernels
+without touching them: a domain half is a contiguous row range of every NHWC matrix, and
+
+  * a kernel that accumulates statistics gets one accumulator per half ([2, SLOTS, nq, C]) and is launched per half,
+  * a kernel that consumes a split activation (``Act.split > 0``, coefficient rows [2, C]) is launched per half,
+  * weight gradients of the two halves are added, the shared gamma / beta gradients are gain-weighted sums.
+
+``DomainSplit`` wraps the kernel binding object (HipKernels, or the tests' torch statement) with exactly that
+rule; the engine's launch sequence stays the one of the plain-BN network.  Launches on unsplit operands with no
+statistics (input gradients, resampling, dropout masks) pass through untouched, on the whole batch.
+"""
+from __future__ import annotations
+
+import torch
+
+from .acts import Act
+
+
+def _rows(t, N, n0, n1):
+    ppi = t.shape[0] // N
+    return t[n0 * ppi:n1 * ppi]
+
+
+class DomainSplit:
+    def __init__(self, kernels):
+        self.K = kernels
+        self.name = getattr(kernels, "name", "kernels") + "+domain-split"
+
+    def __getattr__(self, name):          # everything that needs no split
+        return getattr(self.K, name)
+
+    @staticmethod
+    def _halves(N):
+        n0 = N // 2                        # batchnorm.py:446: batch_size = input.size()[0] // 2
+        return ((0, 0, n0), (1, n0, N))
+
+    @staticmethod
+    def _sub(a: Act, h, n0, n1):
+        if a.split:
+            assert a.split == n0 or a.split == n1, "domain halves of operand and launch disagree"
+            return a.half(h)
+        rows = _rows(a.x, a.N, n0, n1)
+        return Act(rows, n1 - n0, a.H, a.W, a.scale, a.shift, a.act,
+                   None if a.mask is None else _rows(a.mask, a.N, n0, n1), a.mask_scale, a.bn, a.meta)
+
+    # ------------------------------------------------------------------ forward producers
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
+        if not src.split and (stats is None or stats.dim() == 3):
+            return self.K.conv(src, w, ksize, dil, out, bias, addend, stats, origin=origin)
+        for h, n0, n1 in self._halves(src.N):
+            self.K.conv(self._sub(src, h, n0, n1), w, ksize, dil, _rows(out, src.N, n0, n1), bias,
+                        None if addend is None else _rows(addend, src.N, n0, n1),
+                        None if stats is None else stats[h], origin=origin)
+
+    def dwconv_fwd(self, src: Act, w9c, stride, dil, border_mode, out, stats=None):
+        if not src.split and (stats is None or stats.dim() == 3):
+            return self.K.dwconv_fwd(src, w9c, stride, dil, border_mode, out, stats)
+        for h, n0, n1 in self._halves(src.N):
+            self.K.dwconv_fwd(self._sub(src, h, n0, n1), w9c, stride, dil, border_mode, _rows(out, src.N, n0, n1),
+                              None if stats is None else stats[h])
+
+    def stem_fwd(self, x, w, out, stats=None):
+        if stats is None or stats.dim() == 3:
+            return self.K.stem_fwd(x, w, out, stats)
+        N = x.shape[0]
+        for h, n0, n1 in self._halves(N):
+            self.K.stem_fwd(x[n0:n1], w, _rows(out, N, n0, n1), stats[h])
+
+    def colstats(self, x, stats, N=None):
+        if stats.dim() == 3:
+            return self.K.colstats(x, stats)
+        for h, n0, n1 in self._halves(N):
+            self.K.colstats(_rows(x, N, n0, n1), stats[h])
+
+    def bn_apply(self, src: Act, out, residual=None):
+        if not src.split:
+            return self.K.bn_apply(src, out, residual)
+        for h, n0, n1 in self._halves(src.N):
+            self.K.bn_apply(src.half(h), _rows(out, src.N, n0, n1),
+                            None if residual is None else _rows(residual, src.N, n0, n1))
+
+    # ------------------------------------------------------------------ backward
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
+        if not src.split:
+            return self.K.conv_wgrad(src, dy, ksize, dil, dw, origin=origin)
+        d1 = torch.empty_like(dw)
+        for (h, n0, n1), dst in zip(self._halves(src.N), (dw, d1)):
+            self.K.conv_wgrad(src.half(h), _rows(dy, src.N, n0, n1), ksize, dil, dst, origin=origin)
+        dw.add_(d1)
+
+    def dwconv_wgrad(self, src: Act, dy, stride, dil, border_mode, dw):
+        if not src.split:
+            return self.K.dwconv_wgrad(src, dy, stride, dil, border_mode, dw)
+        d1 = torch.empty_like(dw)
+        for (h, n0, n1), dst in zip(self._halves(src.N), (dw, d1)):
+            self.K.dwconv_wgrad(src.half(h), _rows(dy, src.N, n0, n1), stride, dil, border_mode, dst)
+        dw.add_(d1)
+
+    def bnbwd_reduce(self, dU, y: Act, sums):
+        if not y.split:
+            return self.K.bnbwd_reduce(dU, y, sums)
+        for h, n0, n1 in self._halves(y.N):
+            self.K.bnbwd_reduce(_rows(dU, y.N, n0, n1), y.half(h), sums[h])
+
+    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
+        if not y.split:
+            return self.K.bnbwd_finalize(sums, y, c1, c2, dgamma, dbeta)
+        for h in (0, 1):
+            self.K.bnbwd_finalize(sums[h], y.half(h), c1[h], c2[h], dgamma[h], dbeta[h])
+
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None):
+        if not y.split:
+            return self.K.bnbwd_apply(dU, y, c1, c2, out, addend)
+        for h, n0, n1 in self._halves(y.N):
+            self.K.bnbwd_apply(_rows(dU, y.N, n0, n1), y.half(h), c1[h], c2[h], _rows(out, y.N, n0, n1),
+                               None if addend is None else _rows(addend, y.N, n0, n1))

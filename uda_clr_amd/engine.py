@@ -28,6 +28,7 @@ from typing import Dict, Optional
 import torch
 
 from .acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, BNRec, nchw_view, round4
+from .domain_split import DomainSplit
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -73,11 +74,13 @@ class _Arena:
         self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=like.device)
         self.off = 0
 
-    def take(self, nq, C):
-        n = STAT_SLOTS * nq * C
+    def take(self, nq, C, halves=1):
+        """[SLOTS, nq, C], or [2, SLOTS, nq, C] (one accumulator per domain half, TransNorm)."""
+        n = halves * STAT_SLOTS * nq * C
         if self.off + n > self.buf.numel():
             raise RuntimeError("statistics arena exhausted")
-        v = self.buf[self.off:self.off + n].view(STAT_SLOTS, nq, C)
+        v = self.buf[self.off:self.off + n]
+        v = v.view(STAT_SLOTS, nq, C) if halves == 1 else v.view(halves, STAT_SLOTS, nq, C)
         self.off += n
         return v
 
@@ -116,8 +119,14 @@ def resnet_plan(output_stride: int = 16, layers=(3, 4, 23)):
 
 
 class GeneratorEngine:
-    def __init__(self, kernels, output_stride: int = 16, seed: int = 1337, backbone: str = "mobilenet"):
-        self.K = kernels
+    def __init__(self, kernels, output_stride: int = 16, seed: int = 1337, backbone: str = "mobilenet",
+                 transnorm: bool = False):
+        # TransNorm (--use_TN, networks/sync_batchnorm/batchnorm.py:436-520): training batches are normalised per
+        # domain half; the same launch sequence runs through DomainSplit, which issues per-half launches
+        self.tn = bool(transnorm)
+        if self.tn and backbone != "mobilenet":
+            raise NotImplementedError("TransNorm is built for the mobilenet backbone")
+        self.K = DomainSplit(kernels) if self.tn else kernels
         self.os = output_stride
         self.backbone = backbone
         self.dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
@@ -150,7 +159,7 @@ class GeneratorEngine:
         return self._empty(x, P, round4(C))[:, :C]
 
     def _stats(self, ctx, C, training):
-        return ctx.arena.take(2, C) if training else None
+        return ctx.arena.take(2, C, 2 if self.tn else 1) if training else None
 
     def _w(self, ctx, key, kind):
         """Kernel-side layout of a weight, built once per forward context.  (Not cached across forwards: the fused
@@ -168,6 +177,8 @@ class GeneratorEngine:
             q1=False) -> Optional[BNRec]:
         p = ctx.params
         g, b = p[prefix + ".weight"], p[prefix + ".bias"]
+        if self.tn:
+            return self._tn(ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1)
         rm, rv = p[prefix + ".running_mean"], p[prefix + ".running_var"]
         if training:
             if count <= 1:
@@ -183,12 +194,43 @@ class GeneratorEngine:
         self.K.bn_eval_coeffs(g, b, rm, rv, BN_EPS, scale, shift)
         return None
 
+    def _tn(self, ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1):
+        """TransNorm coefficients.  Training: scale / shift / mean / invstd are [2, C] (row h = domain half h), the
+        halves' counts split ``count`` like the images (N//2 first); eval: plain [C] coefficients."""
+        p, K = ctx.params, self.K
+        g, b = p[prefix + ".weight"], p[prefix + ".bias"]
+        rms, rvs = p[prefix + ".running_mean_source"], p[prefix + ".running_var_source"]
+        rmt, rvt = p[prefix + ".running_mean_target"], p[prefix + ".running_var_target"]
+        if not training:
+            K.tn_eval_coeffs(g, b, rms, rvs, rmt, rvt, BN_EPS, scale, shift)
+            return None
+        N = ctx.N
+        n0 = N // 2
+        per_image = count // N
+        counts = (float(n0 * per_image), float((N - n0) * per_image))
+        if min(counts) <= 1:
+            raise ValueError("Expected more than 1 value per channel when training (%s, TransNorm halves of %d and %d "
+                             "images)" % (prefix, n0, N - n0))
+        for h, (rm, rv) in enumerate(((rms, rvs), (rmt, rvt))):
+            K.bn_finalize(stats[h], counts[h], g, b, rm, rv, BN_MOMENTUM, BN_EPS, scale[h], shift[h], mean[h], invstd[h])
+        gain = torch.empty_like(g)
+        K.tn_gain(stats[0], stats[1], counts[0], counts[1], BN_EPS, scale[0], shift[0], scale[1], shift[1], gain)
+        ctx.nbt.append(p[prefix + ".num_batches_tracked"])
+        rec = BNRec(prefix, mean, invstd, counts, q1, gain)
+        ctx.bnlog.append((prefix, rec))
+        return rec
+
+    def _coef(self, x, C, training):
+        """[4, C] (scale, shift, mean, invstd), or [4, 2, C] when a training batch is normalised per domain half."""
+        return self._empty(x, 4, 2, C) if (self.tn and training) else self._empty(x, 4, C)
+
     def _bn_act(self, ctx, prefix, y, N, H, W, stats, count, training, act, mask=None,
                 mask_scale=1.0, q1=False) -> Act:
         C = y.shape[1]
-        coef = self._empty(y, 4, C)
+        coef = self._coef(y, C, training)
         rec = self._bn(ctx, prefix, stats, count, training, coef[0], coef[1], coef[2], coef[3], q1)
-        return Act(y, N, H, W, coef[0], coef[1], act, mask, mask_scale, rec)
+        return Act(y, N, H, W, coef[0], coef[1], act, mask, mask_scale, rec,
+                   split=N // 2 if (self.tn and training) else 0)
 
     def _mask(self, x, name, P, C, N, H, W, training, masks):
         if not training:
@@ -426,7 +468,7 @@ class GeneratorEngine:
             raise ValueError("input height/width must be multiples of 16, got %dx%d" % (Hin, Win))
         ctx.N = N
         if training:
-            ctx.arena = _Arena(x, STAT_SLOTS * 2 * self.bn_channels)
+            ctx.arena = _Arena(x, STAT_SLOTS * 2 * self.bn_channels * (2 if self.tn else 1))
         if self.backbone == "mobilenet":
             a, low = self._mobilenet_forward(ctx, x, training)
         else:
@@ -435,7 +477,8 @@ class GeneratorEngine:
         a17, H16, W16 = a, a.H, a.W
         P16 = N * H16 * W16
         cat = self._empty(x, P16, 1280)
-        coef = self._empty(x, 4, 1280)
+        coef = self._coef(x, 1280, training)        # channel windows below: coef[q][..., sl]
+        split = N // 2 if (self.tn and training) else 0
         brecs = []
         for j, dl in enumerate(self.dils, start=1):
             sl = slice(256 * (j - 1), 256 * j)
@@ -443,8 +486,8 @@ class GeneratorEngine:
             key = "aspp.aspp%d" % j
             K.conv(a17, self._w(ctx, key + ".atrous_conv.weight", "ohwi"), 1 if j == 1 else 3, dl,
                    cat[:, sl], stats=st)
-            brecs.append(self._bn(ctx, key + ".bn", st, P16, training, coef[0, sl], coef[1, sl],
-                                  coef[2, sl], coef[3, sl]))
+            brecs.append(self._bn(ctx, key + ".bn", st, P16, training, coef[0][..., sl], coef[1][..., sl],
+                                  coef[2][..., sl], coef[3][..., sl]))
         gp = self._empty(x, N, self.c_high)
         K.gap_fwd(a17.x, N, gp, 1.0 / (H16 * W16))
         yg = self._empty(x, N, 256)
@@ -452,10 +495,10 @@ class GeneratorEngine:
         gpa = Act(gp, N, 1, 1)
         K.conv(gpa, self._w(ctx, "aspp.global_avg_pool.1.weight", "ohwi"), 1, 1, yg, stats=st)
         sl = slice(1024, 1280)
-        grec = self._bn(ctx, "aspp.global_avg_pool.2", st, N, training, coef[0, sl], coef[1, sl],
-                        coef[2, sl], coef[3, sl])
+        grec = self._bn(ctx, "aspp.global_avg_pool.2", st, N, training, coef[0][..., sl], coef[1][..., sl],
+                        coef[2][..., sl], coef[3][..., sl])
         K.broadcast_rows(yg, N, cat[:, sl], 1.0)
-        catA = Act(cat, N, H16, W16, coef[0], coef[1], ACT_RELU)
+        catA = Act(cat, N, H16, W16, coef[0], coef[1], ACT_RELU, split=split)
         y1 = self._empty(x, P16, 256)
         st = self._stats(ctx, 256, training)
         K.conv(catA, self._w(ctx, "aspp.conv1.weight", "ohwi"), 1, 1, y1, stats=st)
@@ -492,7 +535,7 @@ class GeneratorEngine:
                xf[:, 304:305], bias=params["decoder.last_conv_boundary.8.bias"])
         st = self._stats(ctx, 305, training)
         if training:
-            K.colstats(xf[:, :305], st)
+            K.colstats(xf[:, :305], st, **({"N": N} if self.tn else {}))
         m, ms = self._mask(x, "decoder.last_conv.2", P4, 305, N, H4, W4, training, masks)
         sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
@@ -599,17 +642,27 @@ class GeneratorEngine:
         if y.bn is None:
             raise NotImplementedError("backward through frozen (eval-mode) BatchNorm is not built yet")
         C = y.C
-        sums = ctx.arena.take(3, C)
+        if y.split:
+            # TransNorm: z = (xhat*gamma + beta) * gain per domain half, gain detached (batchnorm.py:495).  The per-half
+            # kernels see gamma*gain as the scale, so dx is already right; the shared gamma / beta collect gain * (per-half sums)
+            sums = ctx.arena.take(3, C, 2)
+            cg = self._empty(dU, 4, 2, C)
+        else:
+            sums = ctx.arena.take(3, C)
+            cg = self._empty(dU, 4, C)
         K.bnbwd_reduce(dU, y, sums)
-        cg = self._empty(dU, 4, C)
         K.bnbwd_finalize(sums, y, cg[0], cg[1], cg[2], cg[3])
         out = dU if out is None else out
         K.bnbwd_apply(dU, y, cg[0], cg[1], out, addend)
+        if y.split:
+            dg, db = (cg[2] * y.bn.gain).sum(0), (cg[3] * y.bn.gain).sum(0)
+        else:
+            dg, db = cg[2], cg[3]
         if keys is None:
             keys = [(y.bn.key, slice(0, C))]
         for key, sl in keys:
-            G[key + ".weight"] = cg[2, sl]
-            G[key + ".bias"] = cg[3, sl]
+            G[key + ".weight"] = dg[sl]
+            G[key + ".bias"] = db[sl]
         return out
 
     def _wgrad(self, ctx, G, key, src: Act, dy, ksize, dil):
@@ -635,7 +688,7 @@ class GeneratorEngine:
         N, Hin, Win, H16, W16, H4, W4 = ctx.dims
         P4, P16 = N * H4 * W4, N * H16 * W16
         G: Dict[str, torch.Tensor] = {}
-        ctx.arena = _Arena(x, STAT_SLOTS * 3 * (self.bn_channels + 64))
+        ctx.arena = _Arena(x, STAT_SLOTS * 3 * (self.bn_channels + 64) * (2 if self.tn else 1))
         D = S["dec"]
         xf = D["xf"]
         # ---- heads (deeplabv3.py:39-40)
@@ -699,14 +752,23 @@ class GeneratorEngine:
         dUc = self._empty(x, P16, 1280)
         self._dgrad(ctx, "aspp.conv1.weight", dy1a, N, H16, W16, 1, 1, dUc)
         coef, cat = A["coef"], A["cat"]
-        c4 = Act(cat[:, :1024], N, H16, W16, coef[0, :1024], coef[1, :1024], ACT_RELU, None, 1.0,
-                 BNRec("aspp", coef[2, :1024], coef[3, :1024], float(P16)))
+        catA = A["catA"]
+        w4, wg = slice(0, 1024), slice(1024, 1280)
+        if catA.split:
+            n0 = catA.split
+            cnt4, cntg = (float(n0 * H16 * W16), float((N - n0) * H16 * W16)), (float(n0), float(N - n0))
+            gain4 = torch.cat([r.gain for r in A["brecs"]])
+            gaing = A["grec"].gain
+        else:
+            cnt4, cntg, gain4, gaing = float(P16), float(N), None, None
+        c4 = Act(cat[:, :1024], N, H16, W16, coef[0][..., w4], coef[1][..., w4], ACT_RELU, None, 1.0,
+                 BNRec("aspp", coef[2][..., w4], coef[3][..., w4], cnt4, False, gain4), split=catA.split)
         keys = [("aspp.aspp%d.bn" % j, slice(256 * (j - 1), 256 * j)) for j in (1, 2, 3, 4)]
         dyc = self._bn_backward(ctx, G, c4, dUc[:, :1024], keys=keys)
         dUg = self._empty(x, N, 256)
         K.gap_fwd(dUc[:, 1024:1280], N, dUg, 1.0)
-        yga = Act(A["yg"], N, 1, 1, coef[0, 1024:], coef[1, 1024:], ACT_RELU, None, 1.0,
-                  BNRec("aspp.global_avg_pool.2", coef[2, 1024:], coef[3, 1024:], float(N)))
+        yga = Act(A["yg"], N, 1, 1, coef[0][..., wg], coef[1][..., wg], ACT_RELU, None, 1.0,
+                  BNRec("aspp.global_avg_pool.2", coef[2][..., wg], coef[3][..., wg], cntg, False, gaing), split=catA.split)
         dyg = self._bn_backward(ctx, G, yga, dUg)
         self._wgrad(ctx, G, "aspp.global_avg_pool.1.weight", A["gpa"], dyg, 1, 1)
         d_gp = self._empty(x, N, self.c_high)

@@ -71,6 +71,8 @@ SYMBOLS = {
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "uda_bn_running_replay": (_I, [_P, _P, _I, _D, _I, _F, _F, _P, _P, _P]),
     "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
+    "uda_tn_gain": (_I, [_P, _P, _I, _D, _D, _F, _P, _P, _P, _P, _P, _P]),
+    "uda_tn_eval_coeffs": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "uda_bn_apply": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
     "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P]),
     "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P]),
@@ -398,6 +400,24 @@ class HipKernels:
             assert t.is_contiguous() and t.numel() == Cc
         self._ck(self.lib.uda_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), Cc,
                                              eps, scale.data_ptr(), shift.data_ptr(), self._stream()))
+
+    def tn_gain(self, stats0, stats1, count0, count1, eps, scale0, shift0, scale1, shift1, gain):
+        Cc = gain.numel()
+        for t in (scale0, shift0, scale1, shift1, gain):
+            assert t.is_contiguous() and t.numel() == Cc
+        for st in (stats0, stats1):
+            assert st.dtype == torch.float64 and st.is_contiguous() and tuple(st.shape) == (STAT_SLOTS, 2, Cc)
+        self._ck(self.lib.uda_tn_gain(stats0.data_ptr(), stats1.data_ptr(), Cc, float(count0), float(count1), eps,
+                                      scale0.data_ptr(), shift0.data_ptr(), scale1.data_ptr(), shift1.data_ptr(),
+                                      gain.data_ptr(), self._stream()))
+
+    def tn_eval_coeffs(self, gamma, beta, rmean_s, rvar_s, rmean_t, rvar_t, eps, scale, shift):
+        Cc = gamma.numel()
+        for t in (gamma, beta, rmean_s, rvar_s, rmean_t, rvar_t, scale, shift):
+            assert t.is_contiguous() and t.numel() == Cc
+        self._ck(self.lib.uda_tn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rmean_s.data_ptr(), rvar_s.data_ptr(),
+                                             rmean_t.data_ptr(), rvar_t.data_ptr(), Cc, eps, scale.data_ptr(),
+                                             shift.data_ptr(), self._stream()))
 
     def bn_apply(self, src: Act, out, residual=None):
         s = self._src(src)

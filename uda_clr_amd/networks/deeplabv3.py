@@ -1,7 +1,8 @@
 """DeepLabV3+ generator (MobileNetV2 or ResNet-101 backbone) - the drop-in for the reference's
 ``networks/deeplabv3.py``.
 
-Same constructor, same ``state_dict`` keys (675 entries incl. the aliased backbone slices), same
+Same constructor, same ``state_dict`` keys (675 entries incl. the aliased backbone slices; 899 with
+``sync_bn=False``, the TransNorm model of ``--use_TN``), same
 seeded initialisation, same 7-tuple from ``forward`` (deeplabv3.py:32-41):
 
     x1, x2, feature, x_bu_feature, x_feature, x1_before, x2_before
@@ -18,6 +19,9 @@ from ._tree import Holder
 from .aspp import build_aspp
 from .backbone import build_backbone
 from .decoder import build_decoder
+from .sync_batchnorm.batchnorm import BatchNorm2d as TransNorm2d
+
+_BN_TYPES = (nn.BatchNorm2d, TransNorm2d)
 
 __all__ = ["DeepLab"]
 
@@ -49,11 +53,13 @@ class DeepLab(Holder):
     def __init__(self, backbone='resnet', output_stride=16, num_classes=21,
                  sync_bn=True, freeze_bn=False, method='prototype'):
         super().__init__()
-        if not sync_bn:
-            raise NotImplementedError("TransNorm (--use_TN) is outside the built hot path (SURVEY.md 8f-3)")
         if num_classes != 2:
             raise NotImplementedError("the fused heads are built for num_classes=2 (cup, disc)")
-        BatchNorm = nn.BatchNorm2d
+        # deeplabv3.py:17-23: sync_bn=True is plain nn.BatchNorm2d, sync_bn=False (--use_TN) is TransNorm
+        self.transnorm = not sync_bn
+        if self.transnorm and backbone != 'mobilenet':
+            raise NotImplementedError("TransNorm is built for the mobilenet backbone (the only one train_use_fix_initial.py builds)")
+        BatchNorm = TransNorm2d if self.transnorm else nn.BatchNorm2d
         self.output_stride = output_stride
         self.backbone_name = backbone
         self.backbone = build_backbone(backbone, output_stride, BatchNorm)
@@ -69,13 +75,13 @@ class DeepLab(Holder):
     # ---------------------------------------------------------------- reference API
     def freeze_bn(self):
         for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d):
+            if isinstance(m, _BN_TYPES):
                 m.eval()
 
     def _lr_params(self, roots):
         for root in roots:
             for m in root.modules():
-                if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                if isinstance(m, (nn.Conv2d,) + _BN_TYPES):
                     for p in m.parameters(recurse=False):
                         if p.requires_grad:
                             yield p
@@ -105,7 +111,9 @@ class DeepLab(Holder):
         that forward are reused and only the dropout-dependent tail is recomputed
         (``GeneratorEngine.mc_forward``); otherwise the passes run as plain forwards."""
         assert self.training, "stochastic passes need training mode (dropout + batch statistics)"
-        for ptr, shape, ectx in self._recent:
+        # TransNorm splits the REPEATED batch into its two copies of x (identical statistics, alpha = 1), not into the
+        # halves of x the grad-mode forward saw: nothing of that forward can be reused, the passes run as plain forwards
+        for ptr, shape, ectx in ([] if self.transnorm else self._recent):
             if ptr == x.data_ptr() and shape == tuple(x.shape):
                 with torch.no_grad():
                     return self._engine_for(x).mc_forward(ectx, reps, passes, masks=masks)
@@ -130,7 +138,7 @@ class DeepLab(Holder):
         return sd
 
     def _bn_training(self):
-        flags = {m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)}
+        flags = {m.training for m in self.modules() if isinstance(m, _BN_TYPES)}
         if len(flags) != 1:
             raise NotImplementedError("mixed train/eval BatchNorm layers are not built")
         flag = flags.pop()
@@ -146,7 +154,8 @@ class DeepLab(Holder):
                                "%s tensor (there is no CPU fallback)" % x.device)
         if self._engine is None:
             from ..kernels import HipKernels
-            self._engine = GeneratorEngine(HipKernels(), self.output_stride, backbone=self.backbone_name)
+            self._engine = GeneratorEngine(HipKernels(), self.output_stride, backbone=self.backbone_name,
+                                           transnorm=self.transnorm)
         return self._engine
 
     def forward(self, input):

@@ -260,6 +260,25 @@ int uda_feat_rank4(const float* wts, const float* coef, int64_t P, int C, float*
 int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* ---- device-side tail of the input pipeline.  The reference's dataloader workers run these per sample
+ * on the CPU with scipy.ndimage; here they run per uint8 BATCH on the GPU, bit-identical to the scipy calls.
+ * uda_normalize_tf: dataloaders/custom_transforms.py:432-466 (Normalize_tf), :414-429 (GetBoundary), :504-507 (ToTensor).
+ *   image_hwc uint8 [B,H,W,3], label uint8 [B,H,W] (grey code: > 200 background, 51..200 disc rim, <= 50 cup) ->
+ *   image f32 [B,3,H,W] = v/127.5 - 1, map f32 [B,2,H,W] (cup, disc), boundary f32 [B,1,H,W] = uint8 Gaussian (sigma 3,
+ *   scipy semantics: axis 0 then axis 1, each truncated to uint8, 'reflect') of the |dilate5 - erode5| ring, / 255.
+ *   gauss_w: HOST pointer to radius+1 doubles, w[0] the centre tap, w[k] the taps at distance k (as numpy computes them). */
+size_t uda_normalize_tf_workspace_bytes(int B, int H, int W);
+int uda_normalize_tf(const uint8_t* image_hwc, const uint8_t* label, int B, int H, int W, const double* gauss_w, int radius,
+                     float* image, float* map, float* boundary, void* workspace, size_t workspace_bytes, void* stream);
+/* custom_transforms.py:95-147 (elastic_transform).  uda_field_smooth: out = alpha * gaussian_filter(noise, sigma,
+ * mode='constant') on [B,H,W] float planes (weights_dev: DEVICE pointer to radius+1 doubles, centre first; tmp: [B,H,W]).
+ * uda_elastic_warp: map_coordinates(order=1) of image (mode 'constant', 0 outside) and label (mode 'nearest') at
+ * (h + dx, w + dy), rounded to uint8; apply (uint8 [B] or null) = 0 copies a sample through. */
+int uda_field_smooth(const float* noise, int B, int H, int W, const double* weights_dev, int radius, float alpha, float* tmp,
+                     float* out, void* stream);
+int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const float* dx, const float* dy, const uint8_t* apply,
+                     int B, int H, int W, uint8_t* image_out, uint8_t* label_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

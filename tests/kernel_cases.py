@@ -771,3 +771,94 @@ CASES += [
     ("wgrad1x1 300->320 P=131072 lazy (256x256 tiles)", case_wgrad(2, 256, 256, 300, 320, 1, 1)),
     ("wgrad2x2 o0 64->256 P=131841 (256x256 tiles)", case_wgrad(1, 363, 363, 64, 256, 2, 1, lazy=False)),
 ]
+
+
+# ---------------------------------------------------------------- input pipeline tail: bit-exact against scipy
+def _fundus_like(B, H, W, g):
+    """uint8 image + grey-coded mask (255 background, 128 disc rim, 0 cup) with ellipses that touch the border in one sample."""
+    import numpy as np
+    rs = np.random.RandomState(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=g)))
+    img = rs.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    lab = np.full((B, H, W), 255, np.uint8)
+    for b in range(B):
+        cy, cx = (0.15 if b == 0 else rs.uniform(0.35, 0.65)) * H, rs.uniform(0.35, 0.65) * W
+        a, c = rs.uniform(0.2, 0.35) * H, rs.uniform(0.2, 0.35) * W
+        r = np.sqrt(((yy - cy) / a) ** 2 + ((xx - cx) / c) ** 2)
+        lab[b][r <= 1.0] = 128
+        lab[b][r <= rs.uniform(0.4, 0.7)] = 0
+        lab[b][rs.rand(H, W) < 0.002] = rs.choice([0, 60, 128, 200, 201, 255])      # isolated pixels, threshold values 50/51/200/201
+        lab[b][0, :7] = 50
+        lab[b][-1, -9:] = 51
+    return img, lab
+
+
+def case_normalize_tf(B, H, W, seed=41):
+    """uda_normalize_tf against the reference's own per-sample arithmetic (custom_transforms.py:414-466: numpy + scipy.ndimage)."""
+    def run(dev):
+        import numpy as np
+        from scipy import ndimage
+        g = gen(seed)
+        img, lab = _fundus_like(B, H, W, g)
+        K = hip()
+        image, mp, bd = K.normalize_tf(torch.from_numpy(img).to(dev), torch.from_numpy(lab).to(dev))
+        worst = 0.0
+        for b in range(B):
+            ri = img[b].astype(np.float32)
+            ri /= 127.5
+            ri -= 1.0
+            cup, disc = (lab[b] <= 50).astype(np.float64), (lab[b] <= 200).astype(np.float64)
+            ring = np.zeros((H, W), bool)
+            for m in (cup, disc):
+                d = ndimage.binary_dilation(m, iterations=5).astype(m.dtype)
+                e = ndimage.binary_erosion(m, iterations=5).astype(m.dtype)
+                s = d + e
+                s[s == 2] = 0
+                ring |= s > 0
+            rb = ndimage.gaussian_filter(ring.astype(np.uint8) * 255, sigma=3) / 255.0
+            exact = (torch.equal(image[b].cpu(), torch.from_numpy(ri.transpose(2, 0, 1).copy())) and
+                     torch.equal(mp[b].cpu(), torch.from_numpy(np.stack([cup, disc])).float()) and
+                     torch.equal(bd[b, 0].cpu(), torch.from_numpy(rb).float()))
+            worst = max(worst, 0.0 if exact else 1.0)
+        return worst, 0.5          # bit-exact or fail
+    return run
+
+
+def case_elastic(B, H, W, seed=43):
+    """uda_field_smooth + uda_elastic_warp against scipy (custom_transforms.py:95-147) on numpy's own uniform draw."""
+    def run(dev):
+        import numpy as np
+        from scipy import ndimage
+        g = gen(seed)
+        img, lab = _fundus_like(B, H, W, g)
+        rs = np.random.RandomState(7)
+        alpha, sigma = 2.0 * W, 0.08 * W
+        noise = np.stack([[rs.rand(H, W) * 2 - 1 for _ in range(B)] for _ in range(2)]).astype(np.float32)
+        K = hip()
+        fld = K.field_smooth(torch.from_numpy(noise).to(dev), sigma, alpha)
+        ref_f = np.stack([[ndimage.gaussian_filter(noise[q, b].astype(np.float64), sigma, mode="constant", cval=0) * alpha
+                           for b in range(B)] for q in range(2)])
+        e_field = float(np.abs(fld.cpu().numpy() - ref_f).max())           # pixels; fp32 storage of a field of up to ~20 px
+        apply = torch.tensor([1] * (B - 1) + [0], dtype=torch.uint8)
+        io, lo = K.elastic_warp(torch.from_numpy(img).to(dev), torch.from_numpy(lab).to(dev), fld[0], fld[1], apply.to(dev))
+        f32 = fld.cpu().numpy().astype(np.float64)                           # the SAME field on both sides: warp must be bit-exact
+        bad = 0
+        gx, gy = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        for b in range(B):
+            if not apply[b]:
+                bad += int((io[b].cpu().numpy() != img[b]).sum() + (lo[b].cpu().numpy() != lab[b]).sum())
+                continue
+            idx = np.reshape(gx + f32[0, b], (-1, 1)), np.reshape(gy + f32[1, b], (-1, 1))
+            ri = np.stack([ndimage.map_coordinates(img[b][:, :, c], idx, order=1).reshape(H, W) for c in range(3)], -1)
+            rl = ndimage.map_coordinates(lab[b], idx, order=1, mode="nearest").reshape(H, W)
+            bad += int((io[b].cpu().numpy() != ri).sum() + (lo[b].cpu().numpy() != rl).sum())
+        return max(e_field / 1e-4, float(bad)), 0.5       # field within 1e-4 px * 0.5, warp bit-exact
+    return run
+
+
+CASES += [
+    ("normalize_tf 3 x 96 x 80 vs scipy (bit-exact)", case_normalize_tf(3, 96, 80)),
+    ("normalize_tf 2 x 512 x 512 vs scipy (bit-exact)", case_normalize_tf(2, 512, 512)),
+    ("elastic field + warp 3 x 96 x 80 vs scipy", case_elastic(3, 96, 80)),
+    ("elastic field + warp 2 x 256 x 256 vs scipy", case_elastic(2, 256, 256)),
+]

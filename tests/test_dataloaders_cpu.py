@@ -41,6 +41,37 @@ def test_dataset_and_transform_chain(tmp_path):
     assert s["map"].sum() > 0 and isinstance(s["img_name"], str)
 
 
+def test_deferred_tail_hands_over_uint8_and_the_trainer_decodes_it(tmp_path, monkeypatch):
+    """UDA_CLR_DEVICE_INPUT=1: Normalize_tf + ToTensor emit the uint8 image and grey mask; TrainerBase._decode turns the batch
+    into image / map / boundary through ops.normalize_tf (here: a stand-in that runs the CPU Normalize_tf, so the plumbing is
+    checked without a GPU; the kernel itself is compared with scipy bit for bit in tests/kernel_cases.py)."""
+    from uda_clr_amd.train_process._common import TrainerBase
+    write_dataset(str(tmp_path), "refuge", "train", 3, size=96, seed=2)
+    chain = lambda: Compose([tr.RandomCrop(96), tr.Normalize_tf(), tr.ToTensor()])
+    plain = DL.FundusSegmentation(base_dir=str(tmp_path), dataset="refuge", split="train", transform=chain())
+    want = next(iter(DataLoader(plain, batch_size=3, shuffle=False, num_workers=0)))
+    monkeypatch.setattr(tr, "DEVICE_TAIL", True)
+    got = next(iter(DataLoader(plain, batch_size=3, shuffle=False, num_workers=0)))
+    assert set(got) == {"image_u8", "label_u8", "img_name"}
+    assert got["image_u8"].dtype == got["label_u8"].dtype == torch.uint8
+    assert got["image_u8"].shape == (3, 96, 96, 3) and got["label_u8"].shape == (3, 96, 96)
+    monkeypatch.setattr(tr, "DEVICE_TAIL", False)
+
+    def cpu_normalize_tf(img_u8, lab_u8):
+        outs = [tr.ToTensor()(tr.Normalize_tf()({"image": i.numpy(), "label": l.numpy(), "img_name": ""}))
+                for i, l in zip(img_u8, lab_u8)]
+        return tuple(torch.stack([o[k] for o in outs]) for k in ("image", "map", "boundary"))
+
+    class T(TrainerBase):
+        def __init__(self):
+            self.ops = type("Ops", (), {"normalize_tf": staticmethod(cpu_normalize_tf)})()
+        def _to(self, t): return t
+    dec = T()._decode(got)
+    for k in ("image", "map", "boundary"):
+        assert torch.equal(dec[k], want[k]), k
+    assert T()._decode(want) is want
+
+
 def test_dropin_publishes_reference_import_names():
     import sys
     install()

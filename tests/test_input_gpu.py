@@ -1,0 +1,67 @@
+"""-m gpu: the device-side tail of the input pipeline inside the Trainer.
+
+A Trainer_baseline epoch over uint8 batches (the deferred tail of dataloaders.custom_transforms with
+UDA_CLR_DEVICE_INPUT=1: uda_normalize_tf decodes on the GPU) must write the same loss rows as the same epoch over the
+float batches the CPU chain produces (numpy + scipy.ndimage, the reference's arithmetic): the decoded tensors are
+bit-identical, so the rows are.  The kernels themselves are compared with scipy in tests/kernel_cases.py."""
+import numpy as np
+import pytest
+import torch
+
+import model_cases
+from kernel_cases import _fundus_like, gen
+from uda_clr_amd import ops
+from uda_clr_amd.dataloaders import custom_transforms as tr
+from uda_clr_amd.train_process import Trainer_baseline
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _batches(n, B, S):
+    out_u8, out_f = [], []
+    for i in range(n):
+        img, lab = _fundus_like(B, S, S, gen(100 + i))
+        out_u8.append({"image_u8": torch.from_numpy(img), "label_u8": torch.from_numpy(lab), "img_name": ["s"] * B})
+        dec = [tr.ToTensor()(tr.Normalize_tf()({"image": img[b], "label": lab[b], "img_name": "s"})) for b in range(B)]
+        out_f.append({k: torch.stack([d[k] for d in dec]) for k in ("image", "map", "boundary")})
+    return out_u8, out_f
+
+
+def _rows(path):
+    with open(path) as f:
+        return [l.split(",") for l in f.read().strip().split("\n")[1:]]
+
+
+def test_trainer_epoch_on_uint8_batches_equals_epoch_on_cpu_decoded_batches(tmp_path):
+    u8, fl = _batches(2, 4, 64)
+    rows = []
+    for tag, loader in (("u8", u8), ("f32", fl)):
+        m = model_cases.seeded_model().to(DEV)
+        m._engine_for(torch.empty(1, device=DEV)).seed = 1337            # same dropout streams in both runs
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
+        t = Trainer_baseline.Trainer(cuda=True, model_gen=m, optimizer_gen=opt, lr_gen=1e-3, lr_decrease_rate=0.1,
+                                     val_loader=loader, domain_loaderS=loader, domain_loaderT=loader, out=str(tmp_path / tag),
+                                     max_epoch=1, stop_epoch=1, interval_validate=1, batch_size=4, warmup_epoch=-1)
+        t.epoch = 0
+        t.iteration = 0
+        t.train()
+        t.validate()
+        rows.append(_rows(tmp_path / tag / "log.csv"))
+    a, b = rows
+    assert len(a) == len(b) >= 3
+    for ra, rb in zip(a, b):
+        assert ra[2:8] == rb[2:8], (ra, rb)          # loss columns and the validation tuple, digit for digit
+
+
+def test_elastic_deform_is_identity_where_not_applied_and_moves_pixels_where_applied():
+    img, lab = _fundus_like(4, 128, 128, gen(5))
+    iu, lu = torch.from_numpy(img).to(DEV), torch.from_numpy(lab).to(DEV)
+    apply = torch.tensor([1, 0, 1, 0], dtype=torch.uint8, device=DEV)
+    io, lo = ops.elastic_deform(iu, lu, apply=apply)
+    assert torch.equal(io[1], iu[1]) and torch.equal(lo[3], lu[3])
+    assert not torch.equal(io[0], iu[0]) and not torch.equal(lo[2], lu[2])
+    assert set(torch.unique(lo).tolist()) <= set(range(256))
+    # labels stay a valid grey coding up to bilinear blends along the class borders: most pixels keep a pure class value
+    pure = torch.isin(lo[0], torch.tensor([0, 128, 255], dtype=torch.uint8, device=DEV)).float().mean().item()
+    assert pure > 0.9

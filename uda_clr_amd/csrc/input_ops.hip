@@ -1,0 +1,236 @@
+// Device-side tail of the input pipeline: what the reference's dataloader workers do per sample on
+// the CPU after the random augmentations, done per BATCH on the GPU from the uint8 data instead.
+//
+//   uda_normalize_tf   dataloaders/custom_transforms.py:432-466 (Normalize_tf) + :414-429 (GetBoundary) + :504-507
+//                      (ToTensor): image/127.5 - 1, grey-coded mask -> 2-channel map, boundary = Gaussian(sigma 3) of the
+//                      |dilate5 - erode5| ring of both channels.  The reference calls scipy.ndimage for the morphology and
+//                      the blur; the kernels below restate those algorithms exactly (tests compare with scipy bit for bit):
+//                        * binary_dilation / binary_erosion with the default cross, iterations = 5, border_value = 0
+//                          == dilation / erosion by the L1 ball of radius 5 with zeros outside the image;
+//                        * gaussian_filter on a uint8 array keeps uint8: axis 0 first, each pass accumulates in double in
+//                          correlate1d's symmetric order (centre, then the pairs from the farthest inwards), truncates to
+//                          uint8, mode 'reflect'.
+//   uda_elastic_warp   custom_transforms.py:95-147 (elastic_transform): bilinear map_coordinates of the image (constant 0
+//                      outside) and of the label (nearest edge outside) along a displacement field, rounded to uint8.
+//   uda_field_smooth   the separable Gaussian (mode 'constant') that turns the uniform noise into that displacement field.
+//
+// All kernels are HBM-bound byte work: one coalesced pass per plane, halo rows/columns through LDS or the L2.
+#include "common.h"
+
+// scipy's C loops are compiled without fused multiply-add: a*b + c rounds twice.  The truncations / roundings to uint8 below
+// must see the same doubles (255 * sum(w) is 254.99999999999997 or 255.0 depending on it), so no contraction in this file.
+#pragma clang fp contract(off)
+
+#define NTF_MAXR 16
+
+struct GaussW {
+    double w[NTF_MAXR + 1];     // w[0] centre, w[k] the two taps at distance k
+};
+
+// ------------------------------------------------------------------------------------------ decode
+__global__ __launch_bounds__(256) void ntf_decode_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ lab,
+                                                         int64_t HW, float* __restrict__ image, float* __restrict__ map) {
+    const int b = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const uint8_t* px = img + ((int64_t)b * HW + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) image[((int64_t)b * 3 + c) * HW + p] = (float)px[c] / 127.5f - 1.0f;
+    const int g = lab[(int64_t)b * HW + p];          // > 200 background, 51..200 disc rim, <= 50 cup (inside the disc)
+    map[((int64_t)b * 2 + 0) * HW + p] = g <= 50 ? 1.f : 0.f;
+    map[((int64_t)b * 2 + 1) * HW + p] = g <= 200 ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------ ring
+#define RING_R 5
+#define RING_TH 16
+#define RING_TW 64
+__global__ __launch_bounds__(256) void ntf_ring_kernel(const uint8_t* __restrict__ lab, int H, int W, uint8_t* __restrict__ ring) {
+    __shared__ uint8_t t[RING_TH + 2 * RING_R][RING_TW + 2 * RING_R + 2];       // bit0 cup, bit1 disc; 0 outside the image
+    const int b = blockIdx.z, h0 = blockIdx.y * RING_TH, w0 = blockIdx.x * RING_TW;
+    const uint8_t* L = lab + (int64_t)b * H * W;
+    for (int e = threadIdx.x; e < (RING_TH + 2 * RING_R) * (RING_TW + 2 * RING_R); e += 256) {
+        const int r = e / (RING_TW + 2 * RING_R), c = e % (RING_TW + 2 * RING_R);
+        const int h = h0 + r - RING_R, w = w0 + c - RING_R;
+        uint8_t v = 0;
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const int g = L[(int64_t)h * W + w];
+            v = (g <= 50 ? 1 : 0) | (g <= 200 ? 2 : 0);
+        }
+        t[r][c] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < RING_TH; rr += 4) {
+        const int h = h0 + rr, w = w0 + tx;
+        if (h >= H || w >= W) continue;
+        uint8_t any = 0, all = 3;
+#pragma unroll
+        for (int dy = -RING_R; dy <= RING_R; ++dy) {
+            const int span = RING_R - (dy < 0 ? -dy : dy);
+#pragma unroll
+            for (int dx = -RING_R; dx <= RING_R; ++dx) {
+                if (dx < -span || dx > span) continue;
+                const uint8_t v = t[rr + RING_R + dy][tx + RING_R + dx];
+                any |= v;
+                all &= v;
+            }
+        }
+        ring[((int64_t)b * H + h) * W + w] = (any ^ all) ? 255 : 0;         // dilated but not eroded, in either channel
+    }
+}
+
+// ------------------------------------------------------------------------------------------ uint8 Gaussian, one axis
+__device__ __forceinline__ int reflect_idx(int i, int n) {      // scipy 'reflect': d c b a | a b c d | d c b a
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - 1 - i;
+    return i;
+}
+
+template <int AXIS, bool LAST>
+__global__ __launch_bounds__(256) void ntf_gauss_kernel(const uint8_t* __restrict__ in, int H, int W, GaussW gw, int R,
+                                                        uint8_t* __restrict__ out8, float* __restrict__ outf) {
+    const int b = blockIdx.z, h = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    const uint8_t* I = in + (int64_t)b * H * W;
+    const int n = AXIS == 0 ? H : W, c = AXIS == 0 ? h : w;
+    auto at = [&](int i) -> double {
+        const int j = reflect_idx(i, n);
+        return (double)(AXIS == 0 ? I[(int64_t)j * W + w] : I[(int64_t)h * W + j]);
+    };
+    double tmp = at(c) * gw.w[0];
+    for (int k = R; k >= 1; --k) tmp += (at(c - k) + at(c + k)) * gw.w[k];
+    const uint8_t v = (uint8_t)tmp;                                   // truncation, like the cast into scipy's uint8 output
+    const int64_t o = ((int64_t)b * H + h) * W + w;
+    if (LAST) outf[o] = (float)((double)v / 255.0);
+    else out8[o] = v;
+}
+
+extern "C" size_t uda_normalize_tf_workspace_bytes(int B, int H, int W) { return (size_t)2 * B * H * W + 32; }
+
+extern "C" int uda_normalize_tf(const uint8_t* image_hwc, const uint8_t* label, int B, int H, int W, const double* gauss_w,
+                                int radius, float* image, float* map, float* boundary, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    UDA_REQUIRE(image_hwc && label && gauss_w && image && map && boundary && workspace, "uda_normalize_tf: null argument");
+    UDA_REQUIRE(B > 0 && radius >= 1 && radius <= NTF_MAXR && H > radius && W > radius,
+                "uda_normalize_tf: need B > 0, 1 <= radius <= %d and H, W > radius (got B=%d, %dx%d, radius %d)", NTF_MAXR, B, H, W, radius);
+    UDA_REQUIRE(workspace_bytes >= uda_normalize_tf_workspace_bytes(B, H, W), "uda_normalize_tf: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W;
+    uint8_t* ring = (uint8_t*)workspace;
+    uint8_t* pass1 = ring + (size_t)B * HW;
+    GaussW gw;
+    for (int k = 0; k <= NTF_MAXR; ++k) gw.w[k] = k <= radius ? gauss_w[k] : 0.0;
+    hipLaunchKernelGGL(ntf_decode_kernel, dim3(uda_cdiv(HW, 256), B), dim3(256), 0, st, image_hwc, label, HW, image, map);
+    UDA_LAUNCH_CHECK("ntf_decode");
+    hipLaunchKernelGGL(ntf_ring_kernel, dim3(uda_cdiv(W, RING_TW), uda_cdiv(H, RING_TH), B), dim3(256), 0, st, label, H, W, ring);
+    UDA_LAUNCH_CHECK("ntf_ring");
+    hipLaunchKernelGGL((ntf_gauss_kernel<0, false>), dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, st, ring, H, W, gw, radius, pass1,
+                       (float*)nullptr);
+    UDA_LAUNCH_CHECK("ntf_gauss axis 0");
+    hipLaunchKernelGGL((ntf_gauss_kernel<1, true>), dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, st, pass1, H, W, gw, radius,
+                       (uint8_t*)nullptr, boundary);
+    UDA_LAUNCH_CHECK("ntf_gauss axis 1");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ elastic deformation
+// One separable pass of scipy.ndimage.gaussian_filter(float64 field, sigma, mode='constant', cval=0) along AXIS, on float
+// planes (the weights arrive from the host as computed by numpy; fp32 storage, fp64 accumulation).
+template <int AXIS>
+__global__ __launch_bounds__(256) void field_smooth_kernel(const float* __restrict__ in, int H, int W, const double* __restrict__ wts,
+                                                           int R, float scale, float* __restrict__ out) {
+    const int b = blockIdx.z, h = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    const float* I = in + (int64_t)b * H * W;
+    const int n = AXIS == 0 ? H : W, c = AXIS == 0 ? h : w;
+    const int64_t stride = AXIS == 0 ? W : 1;
+    const float* base = AXIS == 0 ? I + w : I + (int64_t)h * W;
+    double acc = (double)base[(int64_t)c * stride] * wts[0];
+    for (int k = 1; k <= R; ++k) {
+        const int lo = c - k, hi = c + k;
+        const double a = lo >= 0 ? (double)base[(int64_t)lo * stride] : 0.0;
+        const double d = hi < n ? (double)base[(int64_t)hi * stride] : 0.0;
+        acc += (a + d) * wts[k];
+    }
+    out[((int64_t)b * H + h) * W + w] = (float)acc * scale;
+}
+
+extern "C" int uda_field_smooth(const float* noise, int B, int H, int W, const double* weights_dev, int radius, float alpha,
+                                float* tmp, float* out, void* stream) {
+    UDA_REQUIRE(noise && weights_dev && tmp && out && B > 0 && H > 0 && W > 0 && radius >= 1, "uda_field_smooth: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(field_smooth_kernel<0>, dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, st, noise, H, W, weights_dev, radius, 1.f, tmp);
+    UDA_LAUNCH_CHECK("field_smooth axis 0");
+    hipLaunchKernelGGL(field_smooth_kernel<1>, dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, st, tmp, H, W, weights_dev, radius, alpha, out);
+    UDA_LAUNCH_CHECK("field_smooth axis 1");
+    return 0;
+}
+
+// map_coordinates(order=1): bilinear sample at (h + dx[h,w], w + dy[h,w]); the image takes 0 outside ('constant'), the
+// label its nearest edge value ('nearest'); results are rounded to uint8 as scipy does for integer outputs.  `apply[b]` = 0 copies the
+// sample through (the transform fires with p = 0.5 per sample).
+__global__ __launch_bounds__(256) void elastic_warp_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ lab,
+                                                           const float* __restrict__ dx, const float* __restrict__ dy,
+                                                           const uint8_t* __restrict__ apply, int H, int W,
+                                                           uint8_t* __restrict__ img_out, uint8_t* __restrict__ lab_out) {
+    const int b = blockIdx.z, h = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    const int64_t o = ((int64_t)b * H + h) * W + w;
+    const uint8_t* I = img + (int64_t)b * H * W * 3;
+    const uint8_t* L = lab + (int64_t)b * H * W;
+    if (apply && !apply[b]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) img_out[o * 3 + c] = I[((int64_t)h * W + w) * 3 + c];
+        lab_out[o] = L[(int64_t)h * W + w];
+        return;
+    }
+    const double y = (double)h + (double)dx[o], x = (double)w + (double)dy[o];      // the reference adds dx to the ROW index
+    const double fy = floor(y), fx = floor(x);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const double ty = y - fy, tx = x - fx;
+    const double wy[2] = {1.0 - ty, ty}, wx[2] = {1.0 - tx, tx};
+    auto pix = [&](int yy, int xx, int c) -> double {
+        return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (double)I[((int64_t)yy * W + xx) * 3 + c] : 0.0;
+    };
+    // scipy's 'constant' mode: a coordinate outside [0, n-1] gives cval (no blending with the edge); every tap is
+    // value * row weight * column weight, summed in (0,0) (0,1) (1,0) (1,1) order, and integer outputs are ROUNDED (+0.5)
+    const bool inside = y >= 0.0 && y <= (double)(H - 1) && x >= 0.0 && x <= (double)(W - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = 0.0;
+        if (inside) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) v += pix(y0 + i, x0 + j, c) * wy[i] * wx[j];
+        }
+        img_out[o * 3 + c] = (uint8_t)(v + 0.5);
+    }
+    auto labv = [&](int yy, int xx) -> double {
+        yy = min(max(yy, 0), H - 1);
+        xx = min(max(xx, 0), W - 1);
+        return (double)L[(int64_t)yy * W + xx];
+    };
+    const double yc = fmin(fmax(y, 0.0), (double)(H - 1)), xc = fmin(fmax(x, 0.0), (double)(W - 1));    // 'nearest': clamp the coordinate
+    const double gy = floor(yc), gx = floor(xc);
+    const int ly = (int)gy, lx = (int)gx;
+    const double sy = yc - gy, sx = xc - gx;
+    const double vy[2] = {1.0 - sy, sy}, vx[2] = {1.0 - sx, sx};
+    double lv = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) lv += labv(ly + i, lx + j) * vy[i] * vx[j];
+    lab_out[o] = (uint8_t)(lv + 0.5);
+}
+
+extern "C" int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const float* dx, const float* dy,
+                                const uint8_t* apply, int B, int H, int W, uint8_t* image_out, uint8_t* label_out, void* stream) {
+    UDA_REQUIRE(image_hwc && label && dx && dy && image_out && label_out && B > 0 && H > 1 && W > 1, "uda_elastic_warp: bad args");
+    UDA_REQUIRE(image_hwc != image_out && label != label_out, "uda_elastic_warp: cannot run in place");
+    hipLaunchKernelGGL(elastic_warp_kernel, dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, image_hwc, label, dx, dy,
+                       apply, H, W, image_out, label_out);
+    UDA_LAUNCH_CHECK("elastic_warp");
+    return 0;
+}

@@ -7,12 +7,20 @@ Semantics follow dataloaders/custom_transforms.py of the reference (probabilitie
 coding of the masks: >200 background, 51..200 disc rim, <=50 cup; boundary = |dilate - erode| ring of
 width 5, Gaussian sigma 3), written against numpy / PIL / scipy only."""
 import numbers
+import os
 import random
 
 import numpy as np
 import torch
 from PIL import Image, ImageOps
 from scipy import ndimage
+
+
+# UDA_CLR_DEVICE_INPUT=1: the deterministic tail of the chain (Normalize_tf + ToTensor: /127.5 - 1, mask decoding, boundary ring
+# and its Gaussian blur - the scipy.ndimage part of a worker's time) moves to the GPU: the workers hand over the uint8 image
+# and the uint8 grey mask (4x fewer bytes over PCIe), the Trainer decodes the whole batch with uda_normalize_tf, bit-identical
+# to this file's CPU arithmetic (tests/kernel_cases.py::case_normalize_tf).  The entry script stays unchanged.
+DEVICE_TAIL = os.environ.get("UDA_CLR_DEVICE_INPUT", "0") == "1"
 
 
 def _out(sample, image, label):
@@ -161,6 +169,9 @@ class Normalize_tf(object):
         self.get_boundary = GetBoundary()
 
     def __call__(self, sample):
+        if DEVICE_TAIL:
+            return {'image_u8': np.ascontiguousarray(np.array(sample['image']).astype(np.uint8)),
+                    'label_u8': np.ascontiguousarray(np.array(sample['label']).astype(np.uint8)), 'img_name': sample['img_name']}
         img = np.array(sample['image']).astype(np.float32) / 127.5 - 1.0
         grey = np.array(sample['label']).astype(np.uint8)
         cls = np.full(grey.shape, 2, dtype=np.uint8)          # <= 50: cup
@@ -173,6 +184,9 @@ class Normalize_tf(object):
 
 class ToTensor(object):
     def __call__(self, sample):
+        if 'image_u8' in sample:          # deferred tail: uint8 [H,W,3] + uint8 [H,W], decoded per batch on the device
+            return {'image_u8': torch.from_numpy(sample['image_u8']), 'label_u8': torch.from_numpy(sample['label_u8']),
+                    'img_name': sample['img_name']}
         img = torch.from_numpy(np.ascontiguousarray(np.asarray(sample['image'], dtype=np.float32).transpose(2, 0, 1)))
         mp = torch.from_numpy(np.ascontiguousarray(np.asarray(sample['map']).astype(np.uint8).transpose(2, 0, 1))).float()
         bd = torch.from_numpy(np.ascontiguousarray(np.asarray(sample['boundary'], dtype=np.float64).transpose(2, 0, 1))).float()

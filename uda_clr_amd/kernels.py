@@ -97,6 +97,10 @@ SYMBOLS = {
     "uda_feat_dot4": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "uda_feat_rank4": (_I, [_P, _P, _L, _I, _P, _L, _I, _P]),
     "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
+    "uda_normalize_tf_workspace_bytes": (_U, [_I, _I, _I]),
+    "uda_normalize_tf": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _P, _P, _U, _P]),
+    "uda_field_smooth": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _P, _P]),
+    "uda_elastic_warp": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
 
@@ -616,6 +620,61 @@ class HipKernels:
         self._ck(self.lib.uda_feat_rank4(wts.data_ptr(), coef.data_ptr(), P, Cc, d, ldd, int(accumulate), self._stream()))
 
     # ------------------------------------------------------------------ optimiser
+    # ------------------------------------------------------------------ input pipeline tail
+    @staticmethod
+    def gaussian_weights(sigma, radius):
+        """The taps of scipy.ndimage.gaussian_filter1d, computed the way scipy computes them (numpy, float64), centre first."""
+        import numpy as np
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        phi = phi / phi.sum()
+        return phi[radius:].copy()
+
+    def normalize_tf(self, image_u8, label_u8, sigma=3.0):
+        """uint8 [B,H,W,3] + uint8 grey mask [B,H,W] -> (image f32 [B,3,H,W], map f32 [B,2,H,W], boundary f32 [B,1,H,W])."""
+        for t in (image_u8, label_u8):
+            self._dev(t)
+            assert t.dtype == torch.uint8 and t.is_contiguous()
+        B, H, W, ch = image_u8.shape
+        assert ch == 3 and tuple(label_u8.shape) == (B, H, W)
+        radius = int(4.0 * sigma + 0.5)
+        wts = self.gaussian_weights(sigma, radius)
+        dev = image_u8.device
+        image = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+        mp = torch.empty(B, 2, H, W, dtype=torch.float32, device=dev)
+        bd = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        ws = self._ws(image_u8, self.lib.uda_normalize_tf_workspace_bytes(B, H, W))
+        self._ck(self.lib.uda_normalize_tf(image_u8.data_ptr(), label_u8.data_ptr(), B, H, W,
+                                           wts.ctypes.data_as(C.POINTER(C.c_double)), radius, image.data_ptr(), mp.data_ptr(),
+                                           bd.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        return image, mp, bd
+
+    def field_smooth(self, noise, sigma, alpha):
+        """alpha * gaussian_filter(noise, sigma, mode='constant') per [H,W] plane of a float32 [..., H, W] tensor."""
+        self._dev(noise)
+        assert noise.dtype == torch.float32 and noise.is_contiguous()
+        H, W = noise.shape[-2:]
+        radius = int(4.0 * sigma + 0.5)
+        wts = torch.from_numpy(self.gaussian_weights(sigma, radius)).to(noise.device)
+        tmp, out = torch.empty_like(noise), torch.empty_like(noise)
+        self._ck(self.lib.uda_field_smooth(noise.data_ptr(), noise.numel() // (H * W), H, W, wts.data_ptr(), radius, float(alpha),
+                                           tmp.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def elastic_warp(self, image_u8, label_u8, dx, dy, apply=None):
+        for t in (image_u8, label_u8, dx, dy):
+            self._dev(t)
+            assert t.is_contiguous()
+        B, H, W, ch = image_u8.shape
+        assert ch == 3 and tuple(label_u8.shape) == (B, H, W) == tuple(dx.shape) == tuple(dy.shape)
+        assert image_u8.dtype == label_u8.dtype == torch.uint8 and dx.dtype == dy.dtype == torch.float32
+        if apply is not None:
+            assert apply.dtype == torch.uint8 and apply.numel() == B and apply.is_cuda
+        io, lo = torch.empty_like(image_u8), torch.empty_like(label_u8)
+        self._ck(self.lib.uda_elastic_warp(image_u8.data_ptr(), label_u8.data_ptr(), dx.data_ptr(), dy.data_ptr(), _ptr(apply),
+                                           B, H, W, io.data_ptr(), lo.data_ptr(), self._stream()))
+        return io, lo
+
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
         for t in (params, grads, exp_avg, exp_avg_sq):
             self._dev(t)

@@ -171,6 +171,30 @@ def discriminative_loss(feature, centroids, labels, margin=0.01):
     return _DiscriminativeFn.apply(feature, cents, labels, margin)
 
 
+def normalize_tf(image_u8, label_u8):
+    """Device-side ``Normalize_tf`` + ``ToTensor`` (dataloaders/custom_transforms.py:432-466,504-507) of a uint8 batch:
+    image_u8 [B,H,W,3], label_u8 [B,H,W] (grey-coded mask) -> image [B,3,H,W] in [-1,1], map [B,2,H,W], boundary [B,1,H,W].
+    Bit-identical to the scipy.ndimage calls the reference makes per sample on the CPU (tests/test_input_gpu.py)."""
+    return kernels().normalize_tf(image_u8.contiguous(), label_u8.contiguous())
+
+
+def elastic_deform(image_u8, label_u8, apply=None, noise=None, generator=None):
+    """Device-side ``elastic_transform`` (custom_transforms.py:95-147) of a uint8 batch: per sample with ``apply[b]`` set
+    (default: drawn with p = 0.5) a displacement field alpha * gaussian_filter(U(-1,1), sigma), alpha = 2 * W, sigma = 0.08 * W,
+    bilinear resampling of the image (0 outside) and of the label (nearest edge).  ``noise`` ([2,B,H,W] float32 in [-1,1)) injects
+    the uniform fields (parity tests hand over numpy's draw); otherwise they come from torch's device generator - the random
+    STREAM then differs from numpy's, the distribution does not."""
+    K = kernels()
+    B, H, W, _ = image_u8.shape
+    dev = image_u8.device
+    if apply is None:
+        apply = (torch.rand(B, generator=generator) > 0.5).to(torch.uint8).to(dev)
+    if noise is None:
+        noise = torch.rand(2, B, H, W, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    field = K.field_smooth(noise.contiguous(), 0.08 * W, 2.0 * W)
+    return K.elastic_warp(image_u8.contiguous(), label_u8.contiguous(), field[0], field[1], apply)
+
+
 def photometric_augment(images, generator=None):
     """Device-side photometric augmentation of a [-1,1] image batch in the spirit of utils/Utils.py:33-43
     (brightness/contrast + saturation jitter with p=0.8, grayscale with p=0.2, 5x5 Gaussian blur with

@@ -96,6 +96,7 @@ class Trainer(TrainerBase):
             self.iteration = batch_idx + self.epoch * nS
             assert self.model_gen.training
             self.optim_gen.zero_grad()
+            sampleS = self._decode(sampleS)
             imageS = self._to(sampleS['image'])
             target_map = self._to(sampleS['map'])
             target_boundary = self._to(sampleS['boundary'])

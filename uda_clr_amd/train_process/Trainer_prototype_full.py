@@ -203,6 +203,7 @@ class Trainer(TrainerBase):
         self._set_requires_grad((gen,), True)
         gen_params = [q for q in gen.parameters() if q.requires_grad]
         dis_params = [q for m in (dis, dis2) for q in m.parameters()]
+        sampleS, sampleT = self._decode(sampleS), self._decode(sampleT)
         imageS, target_map = self._to(sampleS['image']), self._to(sampleS['map'])
         target_boundary = self._to(sampleS['boundary'])
         imageT = self._to(sampleT['image'])

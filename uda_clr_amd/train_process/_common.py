@@ -73,6 +73,7 @@ class HipOps:
         self.gen_prototype_retrify = ops.gen_prototype_retrify
         self.discriminative_loss = ops.discriminative_loss
         self.photometric_augment = ops.photometric_augment
+        self.normalize_tf = ops.normalize_tf
         self.consistency_loss = ops.consistency_loss
         self.dice_coeff_2label = metrics.dice_coeff_2label
         self.pixel_acc = metrics.pixel_acc
@@ -159,6 +160,16 @@ class TrainerBase(object):
     def _to(self, t):
         return t.to(self._device(), non_blocking=True)
 
+    def _decode(self, sample):
+        """A batch whose Normalize_tf + ToTensor tail was deferred (dataloaders.custom_transforms.DEVICE_TAIL: uint8 image and
+        grey mask) is decoded here, on the device, for the whole batch; any other sample passes through."""
+        if 'image_u8' not in sample:
+            return sample
+        image, mp, bd = self.ops.normalize_tf(self._to(sample['image_u8']), self._to(sample['label_u8']))
+        out = dict(sample)
+        out.update(image=image, map=mp, boundary=bd)
+        return out
+
     def _log_row(self, fields):
         if self.rank != 0:
             return
@@ -177,6 +188,7 @@ class TrainerBase(object):
         acc = [0.0] * 7
         with torch.no_grad():
             for sample in progress(self.val_loader, total=n, desc='Valid iteration=%d' % self.iteration, ncols=80, leave=False):
+                sample = self._decode(sample)
                 data, target_map = self._to(sample['image']), self._to(sample['map'])
                 predictions = self.model_gen(data)[0]
                 loss = F.binary_cross_entropy_with_logits(predictions, target_map).item()

@@ -260,6 +260,16 @@ int uda_feat_rank4(const float* wts, const float* coef, int64_t P, int C, float*
 int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* ---- "bilinear upsample, then 3x3 conv" without the high-resolution GEMM (networks/decoder.py:50-53 feeding
+ * last_conv_boundary[0], decoder.py:33): the channel mixing of the upsampled part commutes with the interpolation, so the
+ * caller runs the nine tap GEMMs at LOW resolution (g = f W_all^T, [N*h*w, 9*C], tap-major columns) and these kernels do
+ * the interpolation.  fwd: y[p,:] = addend[p % addend_rows,:] + sum_t [p + d_t inside H x W] bilinear(g_t)(p + d_t),
+ * align_corners=True, d_t = ((t/3) - 1, (t%3) - 1) * dil.  bwd: dg = adjoint of that sum applied to dy (gather form). */
+int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, int C, int dil, const float* addend, int64_t ld_add,
+                   int64_t addend_rows, float* y, int64_t ldy, int H, int W, void* stream);
+int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W, int C, int dil, float* dg, int64_t ldg, int h, int w,
+                   void* stream);
+
 /* ---- device-side tail of the input pipeline.  The reference's dataloader workers run these per sample
  * on the CPU with scipy.ndimage; here they run per uint8 BATCH on the GPU, bit-identical to the scipy calls.
  * uda_normalize_tf: dataloaders/custom_transforms.py:432-466 (Normalize_tf), :414-429 (GetBoundary), :504-507 (ToTensor).

@@ -862,3 +862,59 @@ CASES += [
     ("elastic field + warp 3 x 96 x 80 vs scipy", case_elastic(3, 96, 80)),
     ("elastic field + warp 2 x 256 x 256 vs scipy", case_elastic(2, 256, 256)),
 ]
+
+
+# ---------------------------------------------------------------- upsample-then-conv3x3 by low-resolution tap GEMMs + interpolation
+def case_upconv(N, h, w, H, W, C, dil=1, addend_rows=None, seed=47):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        gl = torch.randn(N * h * w, 9 * C, generator=g)
+        ad = None if addend_rows is None else padded(addend_rows, C, g)
+        o_r = padded(N * H * W, C, g)
+        SPEC.upconv_fwd(gl, N, h, w, o_r, H, W, ad, dil)
+        o_h = to_dev(padded(N * H * W, C, g), dev)
+        K.upconv_fwd(gl.to(dev), N, h, w, o_h, H, W, to_dev(ad, dev), dil)
+        errs = [rel(o_h, o_r)]
+        dy = padded(N * H * W, C, g)
+        dg_r = torch.empty(N * h * w, 9 * C)
+        SPEC.upconv_bwd(dy, N, H, W, dg_r, h, w, dil)
+        dg_h = torch.empty(N * h * w, 9 * C, device=dev)
+        K.upconv_bwd(to_dev(dy, dev), N, H, W, dg_h, h, w, dil)
+        errs.append(rel(dg_h, dg_r))
+        return max(errs), 2e-5
+    return run
+
+
+def case_upconv_identity(N, h, w, H, W, Cf, Cl, Cout, seed=48):
+    """The identity the engine relies on: conv3x3(cat(up(f), low)) == upconv(f W_taps^T) + conv3x3_low(low), against
+    F.interpolate + F.conv2d on the same tensors (HIP kernels for every piece)."""
+    def run(dev):
+        import torch.nn.functional as F
+        g = gen(seed)
+        K = hip()
+        f = torch.randn(N, Cf, h, w, generator=g)
+        low = torch.randn(N, Cl, H, W, generator=g)
+        wt = torch.randn(Cout, Cf + Cl, 3, 3, generator=g) / ((Cf + Cl) * 9) ** 0.5
+        ref = F.conv2d(torch.cat([F.interpolate(f, size=(H, W), mode="bilinear", align_corners=True), low], 1), wt, None, 1, 1)
+        ref = ref.permute(0, 2, 3, 1).reshape(N * H * W, Cout)
+        f2 = to_dev(f.permute(0, 2, 3, 1).reshape(N * h * w, Cf).contiguous(), dev)
+        l2 = to_dev(low.permute(0, 2, 3, 1).reshape(N * H * W, Cl).contiguous(), dev)
+        w_taps = wt[:, :Cf].permute(2, 3, 0, 1).reshape(9 * Cout, Cf, 1, 1).contiguous()
+        gl = torch.empty(N * h * w, 9 * Cout, device=dev)
+        K.conv(Act(f2, N, h, w), K.relayout_ohwi(w_taps.to(dev)), 1, 1, gl)
+        y0 = torch.empty(N * H * W, Cout, device=dev)
+        K.conv(Act(l2, N, H, W), K.relayout_ohwi(wt[:, Cf:].contiguous().to(dev)), 3, 1, y0)
+        y = torch.empty(N * H * W, Cout, device=dev)
+        K.upconv_fwd(gl, N, h, w, y, H, W, y0)
+        return rel(y, ref), 2e-5
+    return run
+
+
+CASES += [
+    ("upconv fwd/bwd 2 x (8x8 -> 32x32) x 64", case_upconv(2, 8, 8, 32, 32, 64)),
+    ("upconv fwd/bwd 1 x (5x7 -> 12x20) x 8, addend", case_upconv(1, 5, 7, 12, 20, 8, addend_rows=240)),
+    ("upconv fwd/bwd 4 x (4x4 -> 16x16) x 16, addend shared by 2 reps", case_upconv(4, 4, 4, 16, 16, 16, addend_rows=512)),
+    ("upconv fwd/bwd 1 x (16x16 -> 32x32) x 12 dil 2 (x2, output stride 8)", case_upconv(1, 16, 16, 32, 32, 12, dil=2)),
+    ("upconv identity vs interpolate+conv2d 2 x (8x8 -> 32x32), 64+16 -> 32", case_upconv_identity(2, 8, 8, 32, 32, 64, 16, 32)),
+]

@@ -398,6 +398,33 @@ class SpecKernels:
         t = torch.einsum("Ww,nhWc->nhwc", mw, t)
         dx.copy_(t.reshape(N * h * w, -1))
 
+    @staticmethod
+    def _upconv(g, N, h, w, H, W, C, dil):
+        """sum over the 9 taps of shift_t(upsample(g_t)): upsample each tap plane, read it at p + d_t, zero outside."""
+        mh, mw = _bilinear_matrix(h, H, g.device), _bilinear_matrix(w, W, g.device)
+        t = g.reshape(N, h, w, 9, C)
+        up = torch.einsum("Hh,Ww,nhwtc->ntHWc", mh.to(g.dtype), mw.to(g.dtype), t)
+        out = torch.zeros(N, H, W, C, dtype=g.dtype, device=g.device)
+        for tap in range(9):
+            dh, dw = (tap // 3 - 1) * dil, (tap % 3 - 1) * dil
+            oh0, oh1 = max(0, -dh), min(H, H - dh)
+            ow0, ow1 = max(0, -dw), min(W, W - dw)
+            if oh0 < oh1 and ow0 < ow1:
+                out[:, oh0:oh1, ow0:ow1] += up[:, tap, oh0 + dh:oh1 + dh, ow0 + dw:ow1 + dw]
+        return out.reshape(N * H * W, C)
+
+    def upconv_fwd(self, g, N, h, w, out, H, W, addend=None, dil=1):
+        y = self._upconv(g, N, h, w, H, W, out.shape[1], dil)
+        if addend is not None:
+            y = y + addend.repeat(y.shape[0] // addend.shape[0], 1)
+        out.copy_(y)
+
+    def upconv_bwd(self, dy, N, H, W, dg, h, w, dil=1):
+        with torch.enable_grad():
+            gv = torch.zeros(dg.shape, dtype=dy.dtype, device=dy.device, requires_grad=True)
+            self._upconv(gv, N, h, w, H, W, dy.shape[1], dil).backward(dy)
+        dg.copy_(gv.grad)
+
     def head_upsample_fwd(self, x, N, h, w, out):
         """NHWC [N*h*w, C<=2] -> contiguous NCHW [N, C, H, W] (bilinear, align_corners)."""
         H, W = out.shape[2], out.shape[3]

@@ -6,17 +6,7 @@
 // The backward kernels GATHER (every input pixel re-derives, with the forward's own index
 // arithmetic, which outputs touched it) - deterministic, no float atomics.
 #include "common.h"
-
-// PyTorch's area_pixel_compute_source_index for align_corners=True: src = scale * dst (fp32)
-__device__ __forceinline__ void bil_src(int o, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
-    const float real = scale * (float)o;
-    i0 = (int)real;
-    if (i0 > n_in - 1) i0 = n_in - 1;
-    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
-    l1 = real - (float)i0;
-    l0 = 1.f - l1;
-}
-static inline float bil_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
+#include "bilinear.h"
 
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int h, int w,
                                                            int C, float* __restrict__ out, int64_t ldo, int H, int W,
@@ -41,25 +31,6 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         r.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
         uda_st4(out + p * ldo + cg * 4, r);
     }
-}
-
-// weight with which output index o reads input index i (0 if it does not)
-__device__ __forceinline__ float bil_weight(int o, float scale, int n_in, int i) {
-    int i0, i1;
-    float l0, l1;
-    bil_src(o, scale, n_in, i0, i1, l0, l1);
-    float wgt = 0.f;
-    if (i0 == i) wgt += l0;
-    if (i1 == i) wgt += l1;
-    return wgt;
-}
-// conservative range of outputs that can touch input i
-__device__ __forceinline__ void bil_range(int i, float scale, int n_out, int& lo, int& hi) {
-    if (scale <= 0.f) { lo = 0; hi = n_out - 1; return; }
-    lo = (int)floorf((float)(i - 1) / scale) - 1;
-    hi = (int)ceilf((float)(i + 1) / scale) + 1;
-    if (lo < 0) lo = 0;
-    if (hi > n_out - 1) hi = n_out - 1;
 }
 
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, int64_t ldo, int N, int H, int W,

@@ -1,0 +1,127 @@
+// "Upsample, then 3x3 conv" without the high-resolution GEMM (decoder.py:50-53 + last_conv_boundary[0], decoder.py:33).
+//
+// The decoder's first 3x3 conv reads cat(up4(f), low): 256 bilinearly upsampled ASPP channels and 48 low-level channels.
+// Both the conv and the (align_corners) bilinear upsample are linear and the upsample acts per channel, so for the
+// upsampled part the channel mixing commutes with the interpolation:
+//
+//     conv3x3(up(f))[p, co] = sum_t [p + d_t inside]  up(W_t f)(p + d_t)[co],      t = 9 taps, d_t = tap offset,
+//
+// i.e. nine 256 -> 256 channel GEMMs at the LOW resolution (g = f W_all^T, [P16, 9*256], 1/16 of the pixels: 19 GFLOP
+// instead of 309 at B = 16) followed by this file's interpolation kernel, which is byte work: per output pixel and tap it
+// blends the four low-resolution neighbours of the tap position with the upsample's own weights and adds the result
+// to the conv of the 48 low-level channels (the addend).  Exact reassociation of the same sums - no approximation.
+//
+//   uda_upconv_fwd   y[p, :] = addend[p % addend_rows, :] + sum_t [tap inside] bilinear(g[:, t*C:(t+1)*C])(p + d_t)
+//   uda_upconv_bwd   the adjoint: dG[q, t*C + c] = sum over the high-resolution tap positions that read q (gather: every
+//                    low-resolution pixel re-derives, with the forward's own index arithmetic, who touched it -
+//                    deterministic, no float atomics)
+//
+// Both are bound by cache / HBM bandwidth (36 cached 16-byte reads per 16-byte output in the forward).
+#include "common.h"
+#include "bilinear.h"
+
+__global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict__ g, int64_t ldg, int N, int h, int w, int C,
+                                                         int dil, const float* __restrict__ addend, int64_t ld_add,
+                                                         int64_t add_rows, float* __restrict__ y, int64_t ldy, int H, int W,
+                                                         float sh, float sw) {
+    const int G = C >> 2;
+    const int64_t total = (int64_t)N * H * W * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int64_t p = e / G;
+        const int ow = (int)(p % W), oh = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (addend) acc = uda_ld4(addend + (p % add_rows) * ld_add + cg * 4);
+        const float* gb = g + (int64_t)n * h * w * ldg + cg * 4;
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const int yy = oh + (th - 1) * dil;
+            if (yy < 0 || yy >= H) continue;
+            int h0, h1;
+            float lh0, lh1;
+            bil_src(yy, sh, h, h0, h1, lh0, lh1);
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int xx = ow + (tw - 1) * dil;
+                if (xx < 0 || xx >= W) continue;
+                int w0, w1;
+                float lw0, lw1;
+                bil_src(xx, sw, w, w0, w1, lw0, lw1);
+                const float* gt = gb + (th * 3 + tw) * C;
+                const float4 a00 = uda_ld4(gt + ((int64_t)h0 * w + w0) * ldg), a01 = uda_ld4(gt + ((int64_t)h0 * w + w1) * ldg);
+                const float4 a10 = uda_ld4(gt + ((int64_t)h1 * w + w0) * ldg), a11 = uda_ld4(gt + ((int64_t)h1 * w + w1) * ldg);
+                acc.x += lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
+                acc.y += lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
+                acc.z += lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
+                acc.w += lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
+            }
+        }
+        uda_st4(y + p * ldy + cg * 4, acc);
+    }
+}
+
+extern "C" int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, int C, int dil, const float* addend,
+                              int64_t ld_add, int64_t addend_rows, float* y, int64_t ldy, int H, int W, void* stream) {
+    UDA_REQUIRE(g && y && uda_aligned16(g) && uda_aligned16(y) && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 &&
+                    ldg >= 9 * (int64_t)C && ldy >= C, "uda_upconv_fwd: g must be [N*h*w, >= 9*C], C and lds multiples of 4, 16-byte aligned");
+    UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && dil >= 1, "uda_upconv_fwd: bad geometry");
+    UDA_REQUIRE(!addend || (uda_aligned16(addend) && ld_add % 4 == 0 && ld_add >= C && addend_rows > 0 &&
+                            ((int64_t)N * H * W) % addend_rows == 0),
+                "uda_upconv_fwd: addend must be [addend_rows, >= C] with addend_rows dividing N*H*W");
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(upconv_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, ldg, N, h, w, C, dil, addend, ld_add,
+                       addend ? addend_rows : 1, y, ldy, H, W, bil_scale(h, H), bil_scale(w, W));
+    UDA_LAUNCH_CHECK("upconv_fwd");
+    return 0;
+}
+
+// one thread: 4 channels of one (low-resolution pixel, tap)
+__global__ __launch_bounds__(256) void upconv_bwd_kernel(const float* __restrict__ dy, int64_t ldy, int N, int H, int W, int C,
+                                                         int dil, float* __restrict__ dg, int64_t ldg, int h, int w, float sh,
+                                                         float sw) {
+    const int G = C >> 2;
+    const int64_t total = (int64_t)N * h * w * 9 * G;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(e % G);
+        const int t = (int)((e / G) % 9);
+        const int64_t q = e / ((int64_t)G * 9);
+        const int iw = (int)(q % w), ih = (int)((q / w) % h), n = (int)(q / ((int64_t)w * h));
+        const int dh = (t / 3 - 1) * dil, dw = (t % 3 - 1) * dil;
+        int hlo, hhi, wlo, whi;
+        bil_range(ih, sh, H, hlo, hhi);         // tap positions (inside the image) that can read low-resolution row ih
+        bil_range(iw, sw, W, wlo, whi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int yy = hlo; yy <= hhi; ++yy) {
+            const int oh = yy - dh;             // the output pixel whose tap t sits at yy
+            if (oh < 0 || oh >= H) continue;
+            const float wh = bil_weight(yy, sh, h, ih);
+            if (wh == 0.f) continue;
+            for (int xx = wlo; xx <= whi; ++xx) {
+                const int ow = xx - dw;
+                if (ow < 0 || ow >= W) continue;
+                const float ww = bil_weight(xx, sw, w, iw);
+                if (ww == 0.f) continue;
+                const float4 v = uda_ld4(dy + (((int64_t)n * H + oh) * W + ow) * ldy + cg * 4);
+                const float k = wh * ww;
+                acc.x += k * v.x; acc.y += k * v.y; acc.z += k * v.z; acc.w += k * v.w;
+            }
+        }
+        uda_st4(dg + q * ldg + t * C + cg * 4, acc);
+    }
+}
+
+extern "C" int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W, int C, int dil, float* dg, int64_t ldg, int h,
+                              int w, void* stream) {
+    UDA_REQUIRE(dy && dg && uda_aligned16(dy) && uda_aligned16(dg) && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 &&
+                    ldg >= 9 * (int64_t)C && ldy >= C, "uda_upconv_bwd: dg must be [N*h*w, >= 9*C], C and lds multiples of 4, 16-byte aligned");
+    UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && dil >= 1, "uda_upconv_bwd: bad geometry");
+    const int64_t total = (int64_t)N * h * w * 9 * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(upconv_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, ldy, N, H, W, C, dil, dg, ldg, h, w,
+                       bil_scale(h, H), bil_scale(w, W));
+    UDA_LAUNCH_CHECK("upconv_bwd");
+    return 0;
+}

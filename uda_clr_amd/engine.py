@@ -119,6 +119,8 @@ def resnet_plan(output_stride: int = 16, layers=(3, 4, 23)):
 
 
 class GeneratorEngine:
+    C_FEAT = 256          # channels of the ASPP output that the decoder upsamples (aspp.py:59), the rest of conv0's input is low-level
+
     def __init__(self, kernels, output_stride: int = 16, seed: int = 1337, backbone: str = "mobilenet",
                  transnorm: bool = False):
         # TransNorm (--use_TN, networks/sync_batchnorm/batchnorm.py:436-520): training batches are normalised per
@@ -168,9 +170,18 @@ class GeneratorEngine:
         ck = (key, kind)
         if ck not in ctx.w_cache:
             w = ctx.params[key]
-            ctx.w_cache[ck] = {"ohwi": self.K.relayout_ohwi, "dgrad": self.K.relayout_dgrad,
-                               "dw": self.K.relayout_dw,
-                               "dwflip": lambda t: self.K.relayout_dw(t).flip(0).contiguous()}[kind](w)
+            K, CF = self.K, self.C_FEAT
+
+            def taps(t):            # [O, CF, 3, 3] -> the nine tap matrices stacked along the rows, [(t, o), CF, 1, 1]
+                return t[:, :CF].permute(2, 3, 0, 1).reshape(9 * t.shape[0], CF, 1, 1).contiguous()
+            ctx.w_cache[ck] = {"ohwi": K.relayout_ohwi, "dgrad": K.relayout_dgrad,
+                               "dw": K.relayout_dw,
+                               "dwflip": lambda t: K.relayout_dw(t).flip(0).contiguous(),
+                               # decoder conv0 split into its upsampled-feature part (tap GEMMs at low resolution) and its low-level part
+                               "up_taps": lambda t: K.relayout_ohwi(taps(t)),
+                               "up_taps_dgrad": lambda t: K.relayout_dgrad(taps(t)),
+                               "low_ohwi": lambda t: K.relayout_ohwi(t[:, CF:].contiguous()),
+                               "low_dgrad": lambda t: K.relayout_dgrad(t[:, CF:].contiguous())}[kind](w)
         return ctx.w_cache[ck]
 
     def _bn(self, ctx, prefix, stats, count, training, scale, shift, mean=None, invstd=None,
@@ -243,6 +254,26 @@ class GeneratorEngine:
             self.K.dropout_mask(m, p, self.seed, self.rng_offset)
             self.rng_offset += 1
         return m, 1.0 / (1.0 - p)
+
+    def _conv0(self, ctx, feature, xf, N, H16, W16, H4, W4, out, stats, y0=None):
+        """decoder.last_conv_boundary[0] on cat(up(feature), low) (decoder.py:33,50-53) WITHOUT the high-resolution GEMM over
+        the upsampled channels: conv and bilinear upsample are linear and the upsample acts per channel, so
+        conv3x3(up(f)) = sum_t shift_t(up(f W_t^T)): nine 256 -> 256 GEMMs at 1/16 of the pixels (one 1x1 conv with 9*256
+        outputs) + an interpolation pass (uda_upconv_fwd) that adds them onto the conv of the 48 low-level channels (y0).
+        The same sums re-associated: 19 + 53 GFLOP instead of 367 at B = 16.  ``feature``: [N*H16*W16, 256] (N may be a
+        multiple of the batch y0 was computed on: the MC passes repeat the batch and share y0).  Returns y0."""
+        K, key = self.K, "decoder.last_conv_boundary.0.weight"
+        CF = self.C_FEAT
+        Cout = out.shape[1]
+        if y0 is None:
+            y0 = self._empty(out, out.shape[0], Cout)
+            K.conv(Act(xf[:, CF:CF + 48], N, H4, W4), self._w(ctx, key, "low_ohwi"), 3, 1, y0)
+        g = self._empty(out, feature.shape[0], 9 * Cout)
+        K.conv(Act(feature, N, H16, W16), self._w(ctx, key, "up_taps"), 1, 1, g)
+        K.upconv_fwd(g, N, H16, W16, out, H4, W4, addend=y0)
+        if stats is not None:
+            K.colstats(out, stats, **({"N": N} if self.tn else {}))
+        return y0
 
     # ------------------------------------------------------------------ MobileNetV2 backbone
     def _mobilenet_forward(self, ctx, x, training):
@@ -521,7 +552,7 @@ class GeneratorEngine:
         xbu = Act(xf[:, :304], N, H4, W4)
         yb1 = self._empty(x, P4, 256)
         st = self._stats(ctx, 256, training)
-        K.conv(xbu, self._w(ctx, "decoder.last_conv_boundary.0.weight", "ohwi"), 3, 1, yb1, stats=st)
+        y0 = self._conv0(ctx, feature, xf, N, H16, W16, H4, W4, yb1, st)
         m, ms = self._mask(x, "decoder.last_conv_boundary.3", P4, 256, N, H4, W4, training, masks)
         b1 = self._bn_act(ctx, "decoder.last_conv_boundary.1", yb1, N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
@@ -546,7 +577,7 @@ class GeneratorEngine:
         x2 = self._empty(x, N, 1, Hin, Win)
         K.head_upsample_fwd(x1b, N, H4, W4, x1)
         K.head_upsample_fwd(xf[:, 304:305], N, H4, W4, x2)
-        S["dec"] = dict(low=low, xf=xf, lo=lo, xbu=xbu, b1=b1, b2=b2, sa=sa, x1b=x1b)
+        S["dec"] = dict(low=low, xf=xf, lo=lo, xbu=xbu, b1=b1, b2=b2, sa=sa, x1b=x1b, feature=feature, y0=y0)
         ctx.dims = (N, Hin, Win, H16, W16, H4, W4)
         if ctx.nbt:
             torch._foreach_add_(ctx.nbt, 1)          # num_batches_tracked of all 61 BNs in one launch
@@ -598,7 +629,8 @@ class GeneratorEngine:
             xbu = Act(xf[:, :304], N2, H4, W4)
             yb1 = self._empty(x, reps * P4, 256)
             st = self._stats(ctx, 256, True)
-            K.conv(xbu, self._w(ctx, "decoder.last_conv_boundary.0.weight", "ohwi"), 3, 1, yb1, stats=st)
+            # the low-level part of conv0 (y0) does not depend on a dropout mask: shared by all passes and repetitions
+            self._conv0(ctx, feature, xf, N2, H16, W16, H4, W4, yb1, st, y0=D["y0"])
             m, ms = self._mask(x, "decoder.last_conv_boundary.3", reps * P4, 256, N2, H4, W4, True, mk)
             b1 = self._bn_act(ctx, "decoder.last_conv_boundary.1", yb1, N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
             yb2 = self._empty(x, reps * P4, 256)
@@ -728,10 +760,22 @@ class GeneratorEngine:
         self._dgrad(ctx, "decoder.last_conv_boundary.4.weight", dy2, N, H4, W4, 3, 1, dU1)
         del dU2, dy2
         dy1 = self._bn_backward(ctx, G, b1, dU1)
-        self._wgrad(ctx, G, "decoder.last_conv_boundary.0.weight", D["xbu"], dy1, 3, 1)
-        self._dgrad(ctx, "decoder.last_conv_boundary.0.weight", dy1, N, H4, W4, 3, 1,
-                    d_xf[:, :304], addend=d_xf[:, :304])
-        del dU1, dy1
+        # conv0, split as in _conv0: low-level part on the high-resolution kernels, upsampled part through the adjoint
+        # interpolation (dG) and low-resolution GEMMs
+        key0, CF = "decoder.last_conv_boundary.0.weight", self.C_FEAT
+        w0 = ctx.params[key0]
+        dw_low = self._empty(x, w0.shape[0], w0.shape[1] - CF, 3, 3)
+        K.conv_wgrad(Act(xf[:, CF:304], N, H4, W4), dy1, 3, 1, dw_low)
+        K.conv(Act(dy1, N, H4, W4), self._w(ctx, key0, "low_dgrad"), 3, 1, d_xf[:, CF:304], addend=d_xf[:, CF:304])
+        dG = self._empty(x, P16, 9 * w0.shape[0])
+        K.upconv_bwd(dy1, N, H4, W4, dG, H16, W16)
+        dw_taps = self._empty(x, 9 * w0.shape[0], CF, 1, 1)
+        K.conv_wgrad(Act(D["feature"], N, H16, W16), dG, 1, 1, dw_taps)
+        dw0 = torch.empty_like(w0)
+        dw0[:, :CF] = dw_taps.view(3, 3, w0.shape[0], CF).permute(2, 3, 0, 1)
+        dw0[:, CF:] = dw_low
+        G[key0] = dw0
+        del dU1, dy1, dw_low, dw_taps
         # ---- low-level branch (decoder.py:46-48)
         lo, low = D["lo"], D["low"]
         dylo = self._empty(x, P4, 48)
@@ -743,6 +787,8 @@ class GeneratorEngine:
         d_feat = self._empty(x, P16, 256)
         K.upsample_bwd(d_xf[:, 0:256], N, H4, W4, d_feat, H16, W16)
         del d_xf
+        K.conv(Act(dG, N, H16, W16), self._w(ctx, key0, "up_taps_dgrad"), 1, 1, d_feat, addend=d_feat)
+        del dG
         if gfeat is not None:
             d_feat.add_(_rows(gfeat))
         # ---- ASPP (aspp.py:65-78)

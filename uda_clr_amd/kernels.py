@@ -97,6 +97,8 @@ SYMBOLS = {
     "uda_feat_dot4": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "uda_feat_rank4": (_I, [_P, _P, _L, _I, _P, _L, _I, _P]),
     "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
+    "uda_upconv_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P]),
+    "uda_upconv_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
     "uda_normalize_tf_workspace_bytes": (_U, [_I, _I, _I]),
     "uda_normalize_tf": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _P, _P, _U, _P]),
     "uda_field_smooth": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _P, _P]),
@@ -478,6 +480,27 @@ class HipKernels:
         o, ldo = _mat(dx, "dx")
         assert dout.shape[0] == N * H * W and dx.shape == (N * h * w, dout.shape[1])
         self._ck(self.lib.uda_upsample_bwd(p, ld, N, H, W, dout.shape[1], o, ldo, h, w, self._stream()))
+
+    def upconv_fwd(self, g, N, h, w, out, H, W, addend=None, dil=1):
+        """out[p] = addend[p % addend.rows] + sum over the 9 taps of the bilinear (align_corners) read of g's tap plane at the tap
+        position; g: [N*h*w, 9*C] (tap-major columns), out: [N*H*W, C]."""
+        self._dev(g)
+        Cc = out.shape[1]
+        assert g.shape == (N * h * w, 9 * Cc) and out.shape[0] == N * H * W
+        gp, ldg = _mat(g, "g")
+        o, ldo = _mat(out, "out")
+        ad, lda, rows = (None, 0, 1) if addend is None else (_mat(addend, "addend") + (addend.shape[0],))
+        if addend is not None:
+            assert addend.shape[1] == Cc and (N * H * W) % addend.shape[0] == 0
+        self._ck(self.lib.uda_upconv_fwd(gp, ldg, N, h, w, Cc, dil, ad, lda, rows, o, ldo, H, W, self._stream()))
+
+    def upconv_bwd(self, dy, N, H, W, dg, h, w, dil=1):
+        self._dev(dy)
+        Cc = dy.shape[1]
+        assert dy.shape[0] == N * H * W and dg.shape == (N * h * w, 9 * Cc)
+        d, ldy = _mat(dy, "dy")
+        gp, ldg = _mat(dg, "dg")
+        self._ck(self.lib.uda_upconv_bwd(d, ldy, N, H, W, Cc, dil, gp, ldg, h, w, self._stream()))
 
     def head_upsample_fwd(self, x, N, h, w, out):
         self._dev(x)

@@ -264,9 +264,12 @@ int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * last_conv_boundary[0], decoder.py:33): the channel mixing of the upsampled part commutes with the interpolation, so the
  * caller runs the nine tap GEMMs at LOW resolution (g = f W_all^T, [N*h*w, 9*C], tap-major columns) and these kernels do
  * the interpolation.  fwd: y[p,:] = addend[p % addend_rows,:] + sum_t [p + d_t inside H x W] bilinear(g_t)(p + d_t),
- * align_corners=True, d_t = ((t/3) - 1, (t%3) - 1) * dil.  bwd: dg = adjoint of that sum applied to dy (gather form). */
+ * align_corners=True, d_t = ((t/3) - 1, (t%3) - 1) * dil.  bwd: dg = adjoint of that sum applied to dy (gather form).
+ * stats (double[UDA_STAT_SLOTS][2][C], ADDED into, or null): per-channel sum / sum of squares of y for the next BatchNorm;
+ * uda_upconv_fused_stats tells whether a geometry supports them (otherwise accumulate with uda_colstats). */
+int uda_upconv_fused_stats(int h, int w, int H, int W, int C, int dil);
 int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, int C, int dil, const float* addend, int64_t ld_add,
-                   int64_t addend_rows, float* y, int64_t ldy, int H, int W, void* stream);
+                   int64_t addend_rows, float* y, int64_t ldy, int H, int W, double* stats, void* stream);
 int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W, int C, int dil, float* dg, int64_t ldg, int h, int w,
                    void* stream);
 

@@ -872,10 +872,12 @@ def case_upconv(N, h, w, H, W, C, dil=1, addend_rows=None, seed=47):
         gl = torch.randn(N * h * w, 9 * C, generator=g)
         ad = None if addend_rows is None else padded(addend_rows, C, g)
         o_r = padded(N * H * W, C, g)
-        SPEC.upconv_fwd(gl, N, h, w, o_r, H, W, ad, dil)
+        st_r = torch.zeros(16, 2, C, dtype=torch.float64)
+        SPEC.upconv_fwd(gl, N, h, w, o_r, H, W, ad, dil, st_r)
         o_h = to_dev(padded(N * H * W, C, g), dev)
-        K.upconv_fwd(gl.to(dev), N, h, w, o_h, H, W, to_dev(ad, dev), dil)
-        errs = [rel(o_h, o_r)]
+        st_h = torch.zeros(16, 2, C, dtype=torch.float64, device=dev)
+        K.upconv_fwd(gl.to(dev), N, h, w, o_h, H, W, to_dev(ad, dev), dil, st_h)
+        errs = [rel(o_h, o_r), rel(st_h.sum(0), st_r.sum(0))]
         dy = padded(N * H * W, C, g)
         dg_r = torch.empty(N * h * w, 9 * C)
         SPEC.upconv_bwd(dy, N, H, W, dg_r, h, w, dil)
@@ -915,6 +917,8 @@ CASES += [
     ("upconv fwd/bwd 2 x (8x8 -> 32x32) x 64", case_upconv(2, 8, 8, 32, 32, 64)),
     ("upconv fwd/bwd 1 x (5x7 -> 12x20) x 8, addend", case_upconv(1, 5, 7, 12, 20, 8, addend_rows=240)),
     ("upconv fwd/bwd 4 x (4x4 -> 16x16) x 16, addend shared by 2 reps", case_upconv(4, 4, 4, 16, 16, 16, addend_rows=512)),
-    ("upconv fwd/bwd 1 x (16x16 -> 32x32) x 12 dil 2 (x2, output stride 8)", case_upconv(1, 16, 16, 32, 32, 12, dil=2)),
+    ("upconv fwd/bwd 1 x (16x16 -> 32x32) x 12 dil 2 (pixel kernel + colstats)", case_upconv(1, 16, 16, 32, 32, 12, dil=2)),
+    ("upconv fwd/bwd 2 x (16x16 -> 32x32) x 32 (x2: 4-column strips)", case_upconv(2, 16, 16, 32, 32, 32)),
+    ("upconv fwd/bwd 3 x (32x32 -> 128x128) x 256 (the decoder's shape)", case_upconv(3, 32, 32, 128, 128, 256, addend_rows=16384)),
     ("upconv identity vs interpolate+conv2d 2 x (8x8 -> 32x32), 64+16 -> 32", case_upconv_identity(2, 8, 8, 32, 32, 64, 16, 32)),
 ]

@@ -413,11 +413,13 @@ class SpecKernels:
                 out[:, oh0:oh1, ow0:ow1] += up[:, tap, oh0 + dh:oh1 + dh, ow0 + dw:ow1 + dw]
         return out.reshape(N * H * W, C)
 
-    def upconv_fwd(self, g, N, h, w, out, H, W, addend=None, dil=1):
+    def upconv_fwd(self, g, N, h, w, out, H, W, addend=None, dil=1, stats=None):
         y = self._upconv(g, N, h, w, H, W, out.shape[1], dil)
         if addend is not None:
             y = y + addend.repeat(y.shape[0] // addend.shape[0], 1)
         out.copy_(y)
+        if stats is not None:
+            self.colstats(out, stats)
 
     def upconv_bwd(self, dy, N, H, W, dg, h, w, dil=1):
         with torch.enable_grad():

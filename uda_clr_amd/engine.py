@@ -270,9 +270,11 @@ class GeneratorEngine:
             K.conv(Act(xf[:, CF:CF + 48], N, H4, W4), self._w(ctx, key, "low_ohwi"), 3, 1, y0)
         g = self._empty(out, feature.shape[0], 9 * Cout)
         K.conv(Act(feature, N, H16, W16), self._w(ctx, key, "up_taps"), 1, 1, g)
-        K.upconv_fwd(g, N, H16, W16, out, H4, W4, addend=y0)
-        if stats is not None:
-            K.colstats(out, stats, **({"N": N} if self.tn else {}))
+        if self.tn and stats is not None:          # one accumulator per domain half: a separate statistics pass over the halves' rows
+            K.upconv_fwd(g, N, H16, W16, out, H4, W4, addend=y0)
+            K.colstats(out, stats, N=N)
+        else:
+            K.upconv_fwd(g, N, H16, W16, out, H4, W4, addend=y0, stats=stats)
         return y0
 
     # ------------------------------------------------------------------ MobileNetV2 backbone

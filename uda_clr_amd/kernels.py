@@ -97,7 +97,8 @@ SYMBOLS = {
     "uda_feat_dot4": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "uda_feat_rank4": (_I, [_P, _P, _L, _I, _P, _L, _I, _P]),
     "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
-    "uda_upconv_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P]),
+    "uda_upconv_fused_stats": (_I, [_I, _I, _I, _I, _I, _I]),
+    "uda_upconv_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P, _P]),
     "uda_upconv_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
     "uda_normalize_tf_workspace_bytes": (_U, [_I, _I, _I]),
     "uda_normalize_tf": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _P, _P, _U, _P]),
@@ -481,9 +482,10 @@ class HipKernels:
         assert dout.shape[0] == N * H * W and dx.shape == (N * h * w, dout.shape[1])
         self._ck(self.lib.uda_upsample_bwd(p, ld, N, H, W, dout.shape[1], o, ldo, h, w, self._stream()))
 
-    def upconv_fwd(self, g, N, h, w, out, H, W, addend=None, dil=1):
+    def upconv_fwd(self, g, N, h, w, out, H, W, addend=None, dil=1, stats=None):
         """out[p] = addend[p % addend.rows] + sum over the 9 taps of the bilinear (align_corners) read of g's tap plane at the tap
-        position; g: [N*h*w, 9*C] (tap-major columns), out: [N*H*W, C]."""
+        position; g: [N*h*w, 9*C] (tap-major columns), out: [N*H*W, C]; stats ([SLOTS, 2, C] fp64, added into): column sums
+        and sums of squares of out (fused into the kernel where the geometry allows, a colstats pass otherwise)."""
         self._dev(g)
         Cc = out.shape[1]
         assert g.shape == (N * h * w, 9 * Cc) and out.shape[0] == N * H * W
@@ -492,7 +494,13 @@ class HipKernels:
         ad, lda, rows = (None, 0, 1) if addend is None else (_mat(addend, "addend") + (addend.shape[0],))
         if addend is not None:
             assert addend.shape[1] == Cc and (N * H * W) % addend.shape[0] == 0
-        self._ck(self.lib.uda_upconv_fwd(gp, ldg, N, h, w, Cc, dil, ad, lda, rows, o, ldo, H, W, self._stream()))
+        fused = stats is not None and bool(self.lib.uda_upconv_fused_stats(h, w, H, W, Cc, dil))
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, Cc)
+        self._ck(self.lib.uda_upconv_fwd(gp, ldg, N, h, w, Cc, dil, ad, lda, rows, o, ldo, H, W, _ptr(stats) if fused else None,
+                                         self._stream()))
+        if stats is not None and not fused:
+            self.colstats(out, stats)
 
     def upconv_bwd(self, dy, N, H, W, dg, h, w, dil=1):
         self._dev(dy)

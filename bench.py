@@ -273,7 +273,12 @@ def main():
         if gflop is not None:
             tf = line["value"] / world * gflop / 1e3
             line["step_roofline"] = {"algorithmic_gflop_per_image": gflop, "achieved_tflops_per_gpu": round(tf, 2),
-                                     "mfma_frac": round(tf / 157.3, 4)}
+                                     "mfma_frac": round(tf / 157.3, 4),
+                                     "note": "algorithmic = the REFERENCE's algorithm per counted image (SURVEY.md 8d: full-resolution "
+                                             "decoder conv over the upsampled channels, 4 MC passes as full forwards); the product computes "
+                                             "the same results with fewer executed FLOPs (low-resolution tap GEMMs + interpolation, "
+                                             "MC passes reuse the deterministic part), so this is throughput in reference-FLOP units, "
+                                             "not matrix-pipe utilisation - the kernel-level 'roofline' object is the utilisation figure"}
             if (args.backbone, args.workload) == ("mobilenet", "source_only"):
                 gbs = line["value"] / world * 1.39
                 line["step_roofline"].update(algorithmic_gb_per_image=1.39, achieved_gb_s_per_gpu=round(gbs, 1),

@@ -135,34 +135,95 @@ extern "C" int uda_normalize_tf(const uint8_t* image_hwc, const uint8_t* label, 
 }
 
 // ------------------------------------------------------------------------------------------ elastic deformation
-// One separable pass of scipy.ndimage.gaussian_filter(float64 field, sigma, mode='constant', cval=0) along AXIS, on float
-// planes (the weights arrive from the host as computed by numpy; fp32 storage, fp64 accumulation).
+// One separable pass of scipy.ndimage.gaussian_filter(field, sigma, mode='constant', cval=0) along AXIS on float planes
+// (weights from the host as numpy computes them).  The radius is large (0.32 * side: 164 taps each way at 512), so the
+// operand is staged in LDS once per workgroup and every staged value feeds FS_RUN outputs from registers:
+//   tile = FS_RUN * FS_GROUPS outputs along the smoothed axis x 64 lines across it; a wave's 64 lanes are 64 different
+//   LINES (LDS image [position][line], line stride 65 -> conflict-free for the transposed fill and for the reads),
+//   a thread owns FS_RUN consecutive outputs of its line: out[j] += w[|i - j|] * s[i] while i walks the run + halo once.
+// fp32 accumulation (329 terms of O(1e-2): ~1e-6 relative, i.e. ~1e-5 px of a 4 px displacement).
+#define FS_RUN 8
+#define FS_GROUPS 16
+#define FS_TILE (FS_RUN * FS_GROUPS)       // 128 outputs along the axis per workgroup
+#define FS_LINES 64
+#define FS_LD 65
+
 template <int AXIS>
-__global__ __launch_bounds__(256) void field_smooth_kernel(const float* __restrict__ in, int H, int W, const double* __restrict__ wts,
-                                                           int R, float scale, float* __restrict__ out) {
-    const int b = blockIdx.z, h = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
+__global__ __launch_bounds__(FS_GROUPS * FS_LINES) void field_smooth_kernel(const float* __restrict__ in, int H, int W,
+                                                                            const double* __restrict__ wts, int R, float scale,
+                                                                            float* __restrict__ out) {
+    extern __shared__ float fs_lds[];            // [FS_TILE + 2R][FS_LD] values, then [R + 1] weights
+    const int n = AXIS == 0 ? H : W, m = AXIS == 0 ? W : H;             // smoothed extent, number of lines
+    const int span = FS_TILE + 2 * R;
+    float* wl = fs_lds + (size_t)span * FS_LD;
+    const int b = blockIdx.z, a0 = blockIdx.x * FS_TILE, l0 = blockIdx.y * FS_LINES;
     const float* I = in + (int64_t)b * H * W;
-    const int n = AXIS == 0 ? H : W, c = AXIS == 0 ? h : w;
-    const int64_t stride = AXIS == 0 ? W : 1;
-    const float* base = AXIS == 0 ? I + w : I + (int64_t)h * W;
-    double acc = (double)base[(int64_t)c * stride] * wts[0];
-    for (int k = 1; k <= R; ++k) {
-        const int lo = c - k, hi = c + k;
-        const double a = lo >= 0 ? (double)base[(int64_t)lo * stride] : 0.0;
-        const double d = hi < n ? (double)base[(int64_t)hi * stride] : 0.0;
-        acc += (a + d) * wts[k];
+    const int tid = threadIdx.x;
+    for (int k = tid; k <= R; k += blockDim.x) wl[k] = (float)wts[k];
+    // fill: element (position a0 - R + i, line l0 + l); zeros outside the plane ('constant' mode)
+    if (AXIS == 0) {        // lines are columns: consecutive threads take consecutive columns of one row (coalesced)
+        for (int e = tid; e < span * FS_LINES; e += blockDim.x) {
+            const int i = e / FS_LINES, l = e % FS_LINES;
+            const int pos = a0 - R + i, line = l0 + l;
+            fs_lds[i * FS_LD + l] = (pos >= 0 && pos < n && line < m) ? I[(int64_t)pos * W + line] : 0.f;
+        }
+    } else {                // lines are rows: consecutive threads walk along a row (coalesced), transposed into [position][line]
+        for (int e = tid; e < span * FS_LINES; e += blockDim.x) {
+            const int l = e / span, i = e % span;
+            const int pos = a0 - R + i, line = l0 + l;
+            fs_lds[i * FS_LD + l] = (pos >= 0 && pos < n && line < m) ? I[(int64_t)line * W + pos] : 0.f;
+        }
     }
-    out[((int64_t)b * H + h) * W + w] = (float)acc * scale;
+    __syncthreads();
+    const int l = tid % FS_LINES, grp = tid / FS_LINES;
+    float acc[FS_RUN];
+#pragma unroll
+    for (int j = 0; j < FS_RUN; ++j) acc[j] = 0.f;
+    const int base = grp * FS_RUN;                   // first output of the run, tile-relative; its LDS position is base + R
+    // wr[j] = w(i - j), w(x) = weight at distance |x| (0 beyond R): stepping i shifts the window by one, so every step costs
+    // one new weight (a broadcast LDS read) and one operand read for FS_RUN multiply-adds
+    float wr[FS_RUN];
+#pragma unroll
+    for (int j = 1; j < FS_RUN; ++j) wr[j] = 0.f;
+    wr[0] = wl[R];
+#pragma unroll 8
+    for (int i = -R; i < FS_RUN + R; ++i) {          // i: operand position relative to the run's first output
+        const float v = fs_lds[(base + R + i) * FS_LD + l];
+#pragma unroll
+        for (int j = 0; j < FS_RUN; ++j) acc[j] += wr[j] * v;
+#pragma unroll
+        for (int j = FS_RUN - 1; j > 0; --j) wr[j] = wr[j - 1];
+        const int d = i + 1 < 0 ? -(i + 1) : i + 1;
+        wr[0] = d <= R ? wl[d] : 0.f;
+    }
+    const int line = l0 + l;
+    if (line < m) {
+#pragma unroll
+        for (int j = 0; j < FS_RUN; ++j) {
+            const int pos = a0 + base + j;
+            if (pos < n) out[(int64_t)b * H * W + (AXIS == 0 ? (int64_t)pos * W + line : (int64_t)line * W + pos)] = acc[j] * scale;
+        }
+    }
 }
 
 extern "C" int uda_field_smooth(const float* noise, int B, int H, int W, const double* weights_dev, int radius, float alpha,
                                 float* tmp, float* out, void* stream) {
     UDA_REQUIRE(noise && weights_dev && tmp && out && B > 0 && H > 0 && W > 0 && radius >= 1, "uda_field_smooth: bad args");
+    const size_t lds = ((size_t)(FS_TILE + 2 * radius) * FS_LD + radius + 1) * sizeof(float);
+    UDA_REQUIRE(lds <= 160 * 1024, "uda_field_smooth: radius %d needs %zu B of LDS (limit 160 KiB: sigma up to ~60)", radius, lds);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(field_smooth_kernel<0>, dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, st, noise, H, W, weights_dev, radius, 1.f, tmp);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(field_smooth_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(field_smooth_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess || e1 != hipSuccess) return uda_set_error("uda_field_smooth: cannot reserve LDS: %s", hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+        configured = true;
+    }
+    hipLaunchKernelGGL(field_smooth_kernel<0>, dim3(uda_cdiv(H, FS_TILE), uda_cdiv(W, FS_LINES), B), dim3(FS_GROUPS * FS_LINES), lds, st,
+                       noise, H, W, weights_dev, radius, 1.f, tmp);
     UDA_LAUNCH_CHECK("field_smooth axis 0");
-    hipLaunchKernelGGL(field_smooth_kernel<1>, dim3(uda_cdiv(W, 256), H, B), dim3(256), 0, st, tmp, H, W, weights_dev, radius, alpha, out);
+    hipLaunchKernelGGL(field_smooth_kernel<1>, dim3(uda_cdiv(W, FS_TILE), uda_cdiv(H, FS_LINES), B), dim3(FS_GROUPS * FS_LINES), lds, st,
+                       tmp, H, W, weights_dev, radius, alpha, out);
     UDA_LAUNCH_CHECK("field_smooth axis 1");
     return 0;
 }

@@ -200,38 +200,54 @@ extern "C" int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, 
     return 0;
 }
 
-// one thread: 4 channels of one (low-resolution pixel, tap)
+// one thread: 4 channels of one low-resolution pixel, ALL nine taps: every dy value of the neighbourhood is loaded once and
+// feeds the nine accumulators with the product of its row weight (per vertical tap) and column weight (per horizontal tap) -
+// 16 cached 16-byte reads per 16-byte output at x4 instead of 81 for a thread per (pixel, tap)
 __global__ __launch_bounds__(256) void upconv_bwd_kernel(const float* __restrict__ dy, int64_t ldy, int N, int H, int W, int C,
                                                          int dil, float* __restrict__ dg, int64_t ldg, int h, int w, float sh,
                                                          float sw) {
     const int G = C >> 2;
-    const int64_t total = (int64_t)N * h * w * 9 * G;
+    const int64_t total = (int64_t)N * h * w * G;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(e % G);
-        const int t = (int)((e / G) % 9);
-        const int64_t q = e / ((int64_t)G * 9);
+        const int64_t q = e / G;
         const int iw = (int)(q % w), ih = (int)((q / w) % h), n = (int)(q / ((int64_t)w * h));
-        const int dh = (t / 3 - 1) * dil, dw = (t % 3 - 1) * dil;
         int hlo, hhi, wlo, whi;
-        bil_range(ih, sh, H, hlo, hhi);         // tap positions (inside the image) that can read low-resolution row ih
+        bil_range(ih, sh, H, hlo, hhi);         // tap positions (inside the image) that can read low-resolution row ih / column iw
         bil_range(iw, sw, W, wlo, whi);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int yy = hlo; yy <= hhi; ++yy) {
-            const int oh = yy - dh;             // the output pixel whose tap t sits at yy
-            if (oh < 0 || oh >= H) continue;
-            const float wh = bil_weight(yy, sh, h, ih);
-            if (wh == 0.f) continue;
-            for (int xx = wlo; xx <= whi; ++xx) {
-                const int ow = xx - dw;
-                if (ow < 0 || ow >= W) continue;
-                const float ww = bil_weight(xx, sw, w, iw);
-                if (ww == 0.f) continue;
-                const float4 v = uda_ld4(dy + (((int64_t)n * H + oh) * W + ow) * ldy + cg * 4);
-                const float k = wh * ww;
-                acc.x += k * v.x; acc.y += k * v.y; acc.z += k * v.z; acc.w += k * v.w;
+        float4 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = max(hlo - dil, 0); oh <= min(hhi + dil, H - 1); ++oh) {
+            float a3[3];
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                const int yy = oh + (th - 1) * dil;              // where output row oh's tap th sits
+                a3[th] = (yy >= 0 && yy < H) ? bil_weight(yy, sh, h, ih) : 0.f;
+            }
+            if (a3[0] == 0.f && a3[1] == 0.f && a3[2] == 0.f) continue;
+            const float* row = dy + (((int64_t)n * H + oh) * W) * ldy + cg * 4;
+            for (int ow = max(wlo - dil, 0); ow <= min(whi + dil, W - 1); ++ow) {
+                float b3[3];
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                    const int xx = ow + (tw - 1) * dil;
+                    b3[tw] = (xx >= 0 && xx < W) ? bil_weight(xx, sw, w, iw) : 0.f;
+                }
+                if (b3[0] == 0.f && b3[1] == 0.f && b3[2] == 0.f) continue;
+                const float4 v = uda_ld4(row + (int64_t)ow * ldy);
+#pragma unroll
+                for (int th = 0; th < 3; ++th)
+#pragma unroll
+                    for (int tw = 0; tw < 3; ++tw) {
+                        const float k = a3[th] * b3[tw];
+                        float4& r = acc[th * 3 + tw];
+                        r.x += k * v.x; r.y += k * v.y; r.z += k * v.z; r.w += k * v.w;
+                    }
             }
         }
-        uda_st4(dg + q * ldg + t * C + cg * 4, acc);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) uda_st4(dg + q * ldg + t * C + cg * 4, acc[t]);
     }
 }
 
@@ -240,7 +256,7 @@ extern "C" int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W,
     UDA_REQUIRE(dy && dg && uda_aligned16(dy) && uda_aligned16(dg) && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 &&
                     ldg >= 9 * (int64_t)C && ldy >= C, "uda_upconv_bwd: dg must be [N*h*w, >= 9*C], C and lds multiples of 4, 16-byte aligned");
     UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && dil >= 1, "uda_upconv_bwd: bad geometry");
-    const int64_t total = (int64_t)N * h * w * 9 * (C / 4);
+    const int64_t total = (int64_t)N * h * w * (C / 4);
     int grid = uda_cdiv(total, 256);
     if (grid > 65536) grid = 65536;
     hipLaunchKernelGGL(upconv_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, ldy, N, H, W, C, dil, dg, ldg, h, w,

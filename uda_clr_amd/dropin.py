@@ -22,6 +22,8 @@ _MAP = {
     "networks.aspp": "uda_clr_amd.networks.aspp",
     "networks.decoder": "uda_clr_amd.networks.decoder",
     "networks.backbone": "uda_clr_amd.networks.backbone",
+    "networks.sync_batchnorm": "uda_clr_amd.networks.sync_batchnorm",
+    "networks.sync_batchnorm.batchnorm": "uda_clr_amd.networks.sync_batchnorm.batchnorm",
     "train_process": "uda_clr_amd.train_process",
     "train_process.Trainer": "uda_clr_amd.train_process.Trainer",
     "train_process.Trainer_baseline": "uda_clr_amd.train_process.Trainer_baseline",

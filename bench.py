@@ -270,6 +270,11 @@ def main():
         # i.e. the 4 MC passes counted as full forwards although the fast path recomputes only their stochastic tail)
         gflop = {("mobilenet", "source_only"): 158.2, ("mobilenet", "prototype_full"): 478.0,
                  ("resnet", "source_only"): 531.0}.get((args.backbone, args.workload))
+        # FLOPs the product actually executes per counted image: generator pass 2 * (5.225 backbone/ASPP/1x1 +
+        # 2.416 conv0 as low-level 3x3 + tap GEMM + 9.664 conv4) GMAC forward, x3 with the backward = 103.8 GFLOP; an MC image-pass
+        # 2 * (0.604 tap GEMM + 9.664 conv4) = 20.6 GFLOP; discriminators 217 GFLOP per image pair:
+        # prototype_full (2 * 103.8 + 8 * 20.6 + 217) / 2 = 294.7 GFLOP per counted image
+        executed = {("mobilenet", "source_only"): 103.8, ("mobilenet", "prototype_full"): 294.7}.get((args.backbone, args.workload))
         if gflop is not None:
             tf = line["value"] / world * gflop / 1e3
             line["step_roofline"] = {"algorithmic_gflop_per_image": gflop, "achieved_tflops_per_gpu": round(tf, 2),
@@ -279,6 +284,10 @@ def main():
                                              "the same results with fewer executed FLOPs (low-resolution tap GEMMs + interpolation, "
                                              "MC passes reuse the deterministic part), so this is throughput in reference-FLOP units, "
                                              "not matrix-pipe utilisation - the kernel-level 'roofline' object is the utilisation figure"}
+            if executed is not None and not args.use_tn:
+                tfe = line["value"] / world * executed / 1e3
+                line["step_roofline"].update(executed_gflop_per_image=executed, executed_tflops_per_gpu=round(tfe, 2),
+                                             executed_mfma_frac=round(tfe / 157.3, 4))
             if (args.backbone, args.workload) == ("mobilenet", "source_only"):
                 gbs = line["value"] / world * 1.39
                 line["step_roofline"].update(algorithmic_gb_per_image=1.39, achieved_gb_s_per_gpu=round(gbs, 1),

@@ -289,6 +289,12 @@ int uda_normalize_tf(const uint8_t* image_hwc, const uint8_t* label, int B, int 
  * (h + dx, w + dy), rounded to uint8; apply (uint8 [B] or null) = 0 copies a sample through. */
 int uda_field_smooth(const float* noise, int B, int H, int W, const double* weights_dev, int radius, float alpha, float* tmp,
                      float* out, void* stream);
+/* custom_transforms.py:150-250 (add_salt_pepper_noise, adjust_light, eraser) on a uint8 batch IN PLACE, in that order, with the
+ * per-sample parameters the dataloader workers drew: sp_pos int32 [B, sp_max, 2] (row, column), sp_count int32 [B], sp_value
+ * int32 [B] (1 salt / 0 pepper, as the reference writes them); lut uint8 [B, 256] (identity when adjust_light did not fire);
+ * erase_box int32 [B, 5] = (top, left, height, width, grey level), height 0 = no erasing. */
+int uda_photometric_u8(uint8_t* image_hwc, int B, int H, int W, const int* sp_pos, const int* sp_count, const int* sp_value,
+                       int sp_max, const uint8_t* lut, const int* erase_box, void* stream);
 int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const float* dx, const float* dy, const uint8_t* apply,
                      int B, int H, int W, uint8_t* image_out, uint8_t* label_out, void* stream);
 

@@ -72,6 +72,63 @@ def test_deferred_tail_hands_over_uint8_and_the_trainer_decodes_it(tmp_path, mon
     assert T()._decode(want) is want
 
 
+class _ToNumpy:
+    """what elastic_transform leaves behind when it does not fire (numpy arrays), without its random draw"""
+    def __call__(self, s):
+        return {"image": np.array(s["image"]), "label": np.array(s["label"]), "img_name": s["img_name"]}
+
+
+def _photometric_chain():
+    return Compose([tr.RandomCrop(96), _ToNumpy(), tr.add_salt_pepper_noise(), tr.adjust_light(), tr.eraser(), tr.Normalize_tf(), tr.ToTensor()])
+
+
+def numpy_apply_recorded(s):
+    """CPU statement of what the Trainer does with the recorded outcomes (uda_photometric_u8's arithmetic)."""
+    img = s["image_u8"].numpy().copy()
+    n = int(s["aug_sp_n"][0])
+    pos = s["aug_sp_pos"].numpy()[:n]
+    img[pos[:, 0], pos[:, 1], :] = int(s["aug_sp_val"][0])
+    top, left, h, w, val = [int(v) for v in s["aug_erase"]]
+    out = s["aug_lut"].numpy()[img]
+    if h > 0:
+        out[top:top + h, left:left + w, :] = val
+    return out
+
+
+def test_level2_records_the_same_draws_and_reproduces_the_cpu_chain(tmp_path, monkeypatch):
+    """UDA_CLR_DEVICE_INPUT=2: the workers make the same random draws in the same order but only record them; applying the
+    records (salt/pepper scatter -> gamma table -> erased box) to the uint8 image gives the CPU chain's image byte for byte."""
+    write_dataset(str(tmp_path), "refuge", "train", 4, size=96, seed=3)
+    ds = DL.FundusSegmentation(base_dir=str(tmp_path), dataset="refuge", split="train", transform=_photometric_chain())
+    fired = {"sp": 0, "lut": 0, "erase": 0}
+    for seed in range(6):
+        for idx in range(len(ds)):
+            random.seed(100 * seed + idx); np.random.seed(100 * seed + idx)
+            monkeypatch.setattr(tr, "DEVICE_TAIL", 0)
+            want = ds[idx]
+            random.seed(100 * seed + idx); np.random.seed(100 * seed + idx)
+            monkeypatch.setattr(tr, "DEVICE_TAIL", 2)
+            got = ds[idx]
+            monkeypatch.setattr(tr, "DEVICE_TAIL", 0)
+            assert {"image_u8", "label_u8", "aug_elastic", "aug_sp_pos", "aug_sp_n", "aug_sp_val", "aug_lut", "aug_erase"} <= set(got)
+            ref = tr.ToTensor()(tr.Normalize_tf()({"image": numpy_apply_recorded(got), "label": got["label_u8"].numpy(), "img_name": ""}))
+            for k in ("image", "map", "boundary"):
+                assert torch.equal(ref[k], want[k]), (seed, idx, k)
+            fired["sp"] += int(got["aug_sp_n"][0]) > 0
+            fired["lut"] += not torch.equal(got["aug_lut"], torch.arange(256, dtype=torch.uint8))
+            fired["erase"] += int(got["aug_erase"][2]) > 0
+            # the random state after the sample is the same in both modes: identical consumption of both generators
+    assert all(v > 0 for v in fired.values()), fired
+    # a batch collates (fixed-size records)
+    monkeypatch.setattr(tr, "DEVICE_TAIL", 2)
+    full = Compose([tr.RandomScaleCrop(96), tr.RandomRotate(), tr.RandomFlip(), tr.elastic_transform(), tr.add_salt_pepper_noise(),
+                    tr.adjust_light(), tr.eraser(), tr.Normalize_tf(), tr.ToTensor()])
+    ds2 = DL.FundusSegmentation(base_dir=str(tmp_path), dataset="refuge", split="train", transform=full)
+    b = next(iter(DataLoader(ds2, batch_size=4, shuffle=False, num_workers=0)))
+    assert b["image_u8"].shape == (4, 96, 96, 3) and b["aug_lut"].shape == (4, 256) and b["aug_sp_pos"].shape[0] == 4
+    assert b["aug_elastic"].shape == (4, 1) and b["aug_erase"].shape == (4, 5)
+
+
 def test_dropin_publishes_reference_import_names():
     import sys
     install()

@@ -65,3 +65,42 @@ def test_elastic_deform_is_identity_where_not_applied_and_moves_pixels_where_app
     # labels stay a valid grey coding up to bilinear blends along the class borders: most pixels keep a pure class value
     pure = torch.isin(lo[0], torch.tensor([0, 128, 255], dtype=torch.uint8, device=DEV)).float().mean().item()
     assert pure > 0.9
+
+
+def test_level2_decode_on_the_device_equals_the_cpu_chain(tmp_path, monkeypatch):
+    """UDA_CLR_DEVICE_INPUT=2 through TrainerBase._decode on the HIP kernels: with the recorded photometric outcomes (elastic not
+    fired) the decoded batch equals the CPU chain's tensors exactly; with the elastic transform fired on some samples the others
+    still do and everything stays in range."""
+    import random
+    from torch.utils.data import DataLoader
+    from test_dataloaders_cpu import _photometric_chain, Compose
+    from uda_clr_amd.dataloaders import fundus_dataloader as DL
+    from uda_clr_amd.dataloaders.synthetic import write_dataset
+    from uda_clr_amd.train_process._common import HipOps, TrainerBase
+
+    class T(TrainerBase):
+        def __init__(self):
+            self.ops = HipOps()
+        def _to(self, t): return t.to(DEV)
+
+    write_dataset(str(tmp_path), "refuge", "train", 4, size=128, seed=4)
+    ds = DL.FundusSegmentation(base_dir=str(tmp_path), dataset="refuge", split="train", transform=_photometric_chain())
+    want, got = [], []
+    for idx in range(4):
+        for mode, dst in ((0, want), (2, got)):
+            random.seed(7 + idx); np.random.seed(7 + idx)
+            monkeypatch.setattr(tr, "DEVICE_TAIL", mode)
+            dst.append(ds[idx])
+    monkeypatch.setattr(tr, "DEVICE_TAIL", 0)
+    batch = {k: torch.stack([g[k] for g in got]) for k in got[0] if k != "img_name"}
+    dec = T()._decode(batch)
+    for k in ("image", "map", "boundary"):
+        assert torch.equal(dec[k].cpu(), torch.stack([w[k] for w in want])), k
+    # elastic fired on samples 0 and 2
+    batch["aug_elastic"] = torch.tensor([[1], [0], [1], [0]], dtype=torch.uint8)
+    dec2 = T()._decode(batch)
+    for b in (1, 3):
+        assert torch.equal(dec2["image"][b], dec["image"][b]) and torch.equal(dec2["boundary"][b], dec["boundary"][b])
+    assert not torch.equal(dec2["image"][0], dec["image"][0])
+    assert float(dec2["image"].min()) >= -1.0 and float(dec2["image"].max()) <= 1.0
+    assert bool((dec2["map"][:, 0] <= dec2["map"][:, 1]).all())

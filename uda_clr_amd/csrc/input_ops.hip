@@ -295,3 +295,52 @@ extern "C" int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, 
     UDA_LAUNCH_CHECK("elastic_warp");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------ photometric transforms on uint8 batches
+// custom_transforms.py:150-250 of the reference (add_salt_pepper_noise, adjust_light, eraser), applied in that order with the
+// per-sample random parameters the dataloader workers drew: the positions and the value (1 = "salt", 0 = "pepper": the
+// reference writes 1, not 255) of the noisy pixels, the 256-entry gamma table (identity when the transform did not fire), the
+// erased box and its grey level.
+__global__ __launch_bounds__(256) void salt_pepper_kernel(uint8_t* __restrict__ img, int H, int W, const int* __restrict__ pos,
+                                                          const int* __restrict__ cnt, const int* __restrict__ value, int maxn) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt[b] || i >= maxn) return;
+    const int y = pos[((int64_t)b * maxn + i) * 2], x = pos[((int64_t)b * maxn + i) * 2 + 1];
+    if (y < 0 || y >= H || x < 0 || x >= W) return;
+    uint8_t* p = img + (((int64_t)b * H + y) * W + x) * 3;
+    const uint8_t v = (uint8_t)value[b];
+    p[0] = v; p[1] = v; p[2] = v;
+}
+
+__global__ __launch_bounds__(256) void lut_erase_kernel(uint8_t* __restrict__ img, int H, int W, const uint8_t* __restrict__ lut,
+                                                        const int* __restrict__ box) {
+    __shared__ uint8_t t[256];
+    const int b = blockIdx.y;
+    t[threadIdx.x] = lut[b * 256 + threadIdx.x];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int y = (int)(p / W), x = (int)(p % W);
+    const int top = box[b * 5], left = box[b * 5 + 1], bh = box[b * 5 + 2], bw = box[b * 5 + 3];
+    uint8_t* px = img + ((int64_t)b * H * W + p) * 3;
+    if (bh > 0 && y >= top && y < top + bh && x >= left && x < left + bw) {
+        const uint8_t v = (uint8_t)box[b * 5 + 4];
+        px[0] = v; px[1] = v; px[2] = v;
+    } else {
+        px[0] = t[px[0]]; px[1] = t[px[1]]; px[2] = t[px[2]];
+    }
+}
+
+extern "C" int uda_photometric_u8(uint8_t* image_hwc, int B, int H, int W, const int* sp_pos, const int* sp_count,
+                                  const int* sp_value, int sp_max, const uint8_t* lut, const int* erase_box, void* stream) {
+    UDA_REQUIRE(image_hwc && sp_pos && sp_count && sp_value && lut && erase_box && B > 0 && H > 0 && W > 0 && sp_max >= 0,
+                "uda_photometric_u8: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (sp_max > 0) {
+        hipLaunchKernelGGL(salt_pepper_kernel, dim3(uda_cdiv(sp_max, 256), B), dim3(256), 0, st, image_hwc, H, W, sp_pos, sp_count, sp_value, sp_max);
+        UDA_LAUNCH_CHECK("salt_pepper");
+    }
+    hipLaunchKernelGGL(lut_erase_kernel, dim3(uda_cdiv((int64_t)H * W, 256), B), dim3(256), 0, st, image_hwc, H, W, lut, erase_box);
+    UDA_LAUNCH_CHECK("lut_erase");
+    return 0;
+}

@@ -16,15 +16,31 @@ from PIL import Image, ImageOps
 from scipy import ndimage
 
 
-# UDA_CLR_DEVICE_INPUT=1: the deterministic tail of the chain (Normalize_tf + ToTensor: /127.5 - 1, mask decoding, boundary ring
-# and its Gaussian blur - the scipy.ndimage part of a worker's time) moves to the GPU: the workers hand over the uint8 image
-# and the uint8 grey mask (4x fewer bytes over PCIe), the Trainer decodes the whole batch with uda_normalize_tf, bit-identical
-# to this file's CPU arithmetic (tests/kernel_cases.py::case_normalize_tf).  The entry script stays unchanged.
-DEVICE_TAIL = os.environ.get("UDA_CLR_DEVICE_INPUT", "0") == "1"
+# UDA_CLR_DEVICE_INPUT selects how much of the chain runs on the GPU (the entry script stays unchanged):
+#   1  the deterministic tail (Normalize_tf + ToTensor: /127.5 - 1, mask decoding, boundary ring and its Gaussian blur - the
+#      scipy.ndimage part of a worker's time): the workers hand over the uint8 image and the uint8 grey mask (4x fewer bytes over
+#      PCIe), the Trainer decodes the whole batch with uda_normalize_tf, bit-identical to this file's CPU arithmetic;
+#   2  additionally elastic_transform, add_salt_pepper_noise, adjust_light and eraser: a worker still makes every random draw
+#      of those transforms, in the same order (same consumption of `random` / `np.random` as the CPU chain), but only RECORDS the
+#      outcome (fire / noisy positions and value / gamma table / erased box and grey level); the Trainer applies them to the
+#      batch in the chain's order (uda_field_smooth + uda_elastic_warp, uda_photometric_u8) before decoding.  Given the same
+#      parameters the results equal the CPU chain's byte for byte; only the elastic displacement NOISE comes from the device
+#      generator instead of numpy's (the CPU chain seeds that RandomState from OS entropy, so it has no reproducible stream).
+# The PIL geometry (scale-crop, rotate, flip) stays on the workers.
+DEVICE_TAIL = int(os.environ.get("UDA_CLR_DEVICE_INPUT", "0") or 0)
 
 
-def _out(sample, image, label):
-    return {'image': image, 'label': label, 'img_name': sample['img_name']}
+def _defer(sample, **rec):
+    aug = dict(sample.get('_aug', {}))
+    aug.update(rec)
+    return aug
+
+
+def _out(sample, image, label, aug=None):
+    out = {'image': image, 'label': label, 'img_name': sample['img_name']}
+    if aug is not None or '_aug' in sample:
+        out['_aug'] = aug if aug is not None else sample['_aug']
+    return out
 
 
 class RandomCrop(object):
@@ -86,7 +102,10 @@ class elastic_transform(object):
     numpy arrays behind (image HxWx3 uint8, label HxW uint8)."""
     def __call__(self, sample):
         image, label = np.array(sample['image']), np.array(sample['label'])
-        if random.random() > 0.5:
+        fire = random.random() > 0.5
+        if DEVICE_TAIL >= 2:
+            return _out(sample, image, label, _defer(sample, elastic=fire))
+        if fire:
             side = image.shape[1]
             alpha, sigma = side * 2, side * 0.08
             shape = image.shape[:2]
@@ -107,19 +126,28 @@ class add_salt_pepper_noise(object):
         image = sample['image'].copy()
         amount, salt_vs_pepper = 0.004, 0.2
         seed = random.random()
+        sp = None
         if seed > 0.5:
             n = int(np.ceil(amount * image.size * (salt_vs_pepper if seed > 0.75 else 1.0 - salt_vs_pepper)))
             ys, xs = np.random.randint(0, image.shape[0] - 1, n), np.random.randint(0, image.shape[1] - 1, n)
-            image[ys, xs, :] = 1 if seed > 0.75 else 0
+            sp = (1 if seed > 0.75 else 0, ys, xs)
+            if DEVICE_TAIL < 2:
+                image[ys, xs, :] = sp[0]
+        if DEVICE_TAIL >= 2:
+            return _out(sample, image, sample['label'], _defer(sample, sp=sp))
         return _out(sample, image, sample['label'])
 
 
 class adjust_light(object):
     """gamma correction with gamma ~ U(0.5, 3.5), p = 0.5 (a 256-entry lookup table)"""
     def __call__(self, sample):
+        table = None
         if random.random() > 0.5:
             inv = 1.0 / (random.random() * 3 + 0.5)
             table = (((np.arange(256) / 255.0) ** inv) * 255).astype(np.uint8)
+        if DEVICE_TAIL >= 2:
+            return _out(sample, sample['image'], sample['label'], _defer(sample, lut=table))
+        if table is not None:
             return _out(sample, table[np.asarray(sample['image']).astype(np.uint8)], sample['label'])
         return sample
 
@@ -137,6 +165,8 @@ class eraser(object):
             left, top = np.random.randint(0, W), np.random.randint(0, H)
             if left + w <= W and top + h <= H:
                 break
+        if DEVICE_TAIL >= 2 and not pixel_level:
+            return _out(sample, image, sample['label'], _defer(sample, erase=(top, left, h, w, int(np.random.uniform(v_l, v_h)))))
         image[top:top + h, left:left + w, :] = np.random.uniform(v_l, v_h, (h, w, C)) if pixel_level else np.random.uniform(v_l, v_h)
         return _out(sample, image, sample['label'])
 
@@ -170,8 +200,20 @@ class Normalize_tf(object):
 
     def __call__(self, sample):
         if DEVICE_TAIL:
-            return {'image_u8': np.ascontiguousarray(np.array(sample['image']).astype(np.uint8)),
-                    'label_u8': np.ascontiguousarray(np.array(sample['label']).astype(np.uint8)), 'img_name': sample['img_name']}
+            out = {'image_u8': np.ascontiguousarray(np.array(sample['image']).astype(np.uint8)),
+                   'label_u8': np.ascontiguousarray(np.array(sample['label']).astype(np.uint8)), 'img_name': sample['img_name']}
+            aug = sample.get('_aug')
+            if DEVICE_TAIL >= 2 and aug is not None:            # the recorded outcomes as fixed-size arrays (collate stacks them)
+                maxn = int(np.ceil(0.004 * out['image_u8'].size * 0.8))
+                pos = np.zeros((maxn, 2), np.int32)
+                val, ys, xs = aug.get('sp') or (0, (), ())
+                pos[:len(ys), 0], pos[:len(xs), 1] = ys, xs
+                lut = aug.get('lut')
+                out.update(aug_elastic=np.array([1 if aug.get('elastic') else 0], np.uint8), aug_sp_pos=pos,
+                           aug_sp_n=np.array([len(ys)], np.int32), aug_sp_val=np.array([val], np.int32),
+                           aug_lut=np.arange(256, dtype=np.uint8) if lut is None else lut.astype(np.uint8),
+                           aug_erase=np.array(aug.get('erase') or (0, 0, 0, 0, 0), np.int32))
+            return out
         img = np.array(sample['image']).astype(np.float32) / 127.5 - 1.0
         grey = np.array(sample['label']).astype(np.uint8)
         cls = np.full(grey.shape, 2, dtype=np.uint8)          # <= 50: cup
@@ -184,9 +226,8 @@ class Normalize_tf(object):
 
 class ToTensor(object):
     def __call__(self, sample):
-        if 'image_u8' in sample:          # deferred tail: uint8 [H,W,3] + uint8 [H,W], decoded per batch on the device
-            return {'image_u8': torch.from_numpy(sample['image_u8']), 'label_u8': torch.from_numpy(sample['label_u8']),
-                    'img_name': sample['img_name']}
+        if 'image_u8' in sample:          # deferred tail: uint8 [H,W,3] + uint8 [H,W] (+ recorded augmentation outcomes)
+            return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in sample.items()}
         img = torch.from_numpy(np.ascontiguousarray(np.asarray(sample['image'], dtype=np.float32).transpose(2, 0, 1)))
         mp = torch.from_numpy(np.ascontiguousarray(np.asarray(sample['map']).astype(np.uint8).transpose(2, 0, 1))).float()
         bd = torch.from_numpy(np.ascontiguousarray(np.asarray(sample['boundary'], dtype=np.float64).transpose(2, 0, 1))).float()

@@ -104,6 +104,7 @@ SYMBOLS = {
     "uda_normalize_tf": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _P, _P, _U, _P]),
     "uda_field_smooth": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _P, _P]),
     "uda_elastic_warp": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "uda_photometric_u8": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
 }
 
 
@@ -705,6 +706,21 @@ class HipKernels:
         self._ck(self.lib.uda_elastic_warp(image_u8.data_ptr(), label_u8.data_ptr(), dx.data_ptr(), dy.data_ptr(), _ptr(apply),
                                            B, H, W, io.data_ptr(), lo.data_ptr(), self._stream()))
         return io, lo
+
+    def photometric_u8(self, image_u8, sp_pos, sp_count, sp_value, lut, erase_box):
+        """salt-and-pepper scatter, gamma table and box erasing on a uint8 [B,H,W,3] batch, in place."""
+        self._dev(image_u8)
+        B, H, W, ch = image_u8.shape
+        assert ch == 3 and image_u8.dtype == torch.uint8 and image_u8.is_contiguous()
+        assert sp_pos.dtype == sp_count.dtype == sp_value.dtype == erase_box.dtype == torch.int32 and lut.dtype == torch.uint8
+        assert sp_pos.dim() == 3 and sp_pos.shape[0] == B and sp_pos.shape[2] == 2 and sp_count.numel() == B == sp_value.numel()
+        assert tuple(lut.shape) == (B, 256) and tuple(erase_box.shape) == (B, 5)
+        for t in (sp_pos, sp_count, sp_value, lut, erase_box):
+            assert t.is_cuda and t.is_contiguous()
+        self._ck(self.lib.uda_photometric_u8(image_u8.data_ptr(), B, H, W, sp_pos.data_ptr(), sp_count.data_ptr(),
+                                             sp_value.data_ptr(), sp_pos.shape[1], lut.data_ptr(), erase_box.data_ptr(),
+                                             self._stream()))
+        return image_u8
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
         for t in (params, grads, exp_avg, exp_avg_sq):

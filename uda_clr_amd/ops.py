@@ -195,6 +195,13 @@ def elastic_deform(image_u8, label_u8, apply=None, noise=None, generator=None):
     return K.elastic_warp(image_u8.contiguous(), label_u8.contiguous(), field[0], field[1], apply)
 
 
+def photometric_u8(image_u8, sp_pos, sp_count, sp_value, lut, erase_box):
+    """add_salt_pepper_noise -> adjust_light -> eraser (custom_transforms.py:150-250) on a uint8 batch, in place, with the
+    outcomes the dataloader workers drew (see dataloaders.custom_transforms.DEVICE_TAIL)."""
+    return kernels().photometric_u8(image_u8, sp_pos.contiguous(), sp_count.contiguous().view(-1), sp_value.contiguous().view(-1),
+                                    lut.contiguous(), erase_box.contiguous())
+
+
 def photometric_augment(images, generator=None):
     """Device-side photometric augmentation of a [-1,1] image batch in the spirit of utils/Utils.py:33-43
     (brightness/contrast + saturation jitter with p=0.8, grayscale with p=0.2, 5x5 Gaussian blur with

@@ -74,6 +74,8 @@ class HipOps:
         self.discriminative_loss = ops.discriminative_loss
         self.photometric_augment = ops.photometric_augment
         self.normalize_tf = ops.normalize_tf
+        self.elastic_deform = ops.elastic_deform
+        self.photometric_u8 = ops.photometric_u8
         self.consistency_loss = ops.consistency_loss
         self.dice_coeff_2label = metrics.dice_coeff_2label
         self.pixel_acc = metrics.pixel_acc
@@ -165,7 +167,12 @@ class TrainerBase(object):
         grey mask) is decoded here, on the device, for the whole batch; any other sample passes through."""
         if 'image_u8' not in sample:
             return sample
-        image, mp, bd = self.ops.normalize_tf(self._to(sample['image_u8']), self._to(sample['label_u8']))
+        iu, lu = self._to(sample['image_u8']), self._to(sample['label_u8'])
+        if 'aug_lut' in sample:          # UDA_CLR_DEVICE_INPUT=2: the recorded elastic / photometric outcomes, in the chain's order
+            iu, lu = self.ops.elastic_deform(iu, lu, apply=self._to(sample['aug_elastic']).view(-1))
+            iu = self.ops.photometric_u8(iu.contiguous(), self._to(sample['aug_sp_pos']), self._to(sample['aug_sp_n']),
+                                         self._to(sample['aug_sp_val']), self._to(sample['aug_lut']), self._to(sample['aug_erase']))
+        image, mp, bd = self.ops.normalize_tf(iu, lu)
         out = dict(sample)
         out.update(image=image, map=mp, boundary=bd)
         return out

@@ -92,6 +92,34 @@ def test_transnorm_matches_reference_fixture():
         assert v < tol.get(k, 2e-3 if k.startswith("train.") else 1e-3), (k, v)
 
 
+def test_transnorm_mc_fast_path_equals_plain_stochastic_forwards():
+    """HIP: the repeated batch's deterministic part once on x (repeat_prefix) + the stochastic tail per pass, against the oracle's
+    plain training-mode forwards on x.repeat(2): logits, every running buffer, num_batches_tracked."""
+    from oracle import deeplab_ref
+    B, S, passes = 4, 64, 2
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    m = model_cases.seeded_model(perturb=True, transnorm=True).train()
+    m0 = deeplab_ref.draw_masks(B, S, S, gen)
+    mk = [deeplab_ref.draw_masks(2 * B, S, S, gen) for _ in range(passes)]
+    sd1 = deeplab_ref.canonical_state(m.state_dict())
+    with torch.no_grad():
+        deeplab_ref.deeplab_forward(sd1, x, training=True, masks=m0)            # the grad-mode forward's effect on the buffers
+        ref = torch.cat([deeplab_ref.deeplab_forward(sd1, x.repeat(2, 1, 1, 1), training=True, masks=mk[ps])[0] for ps in range(passes)], 0)
+    m.to(DEV)
+    m.set_dropout_masks(m0)
+    m(x.to(DEV))
+    preds = m.mc_dropout_logits(x.to(DEV), passes=passes, reps=2, masks=mk)
+    assert model_cases.rel(preds, ref) < 1e-3
+    live = m.state_dict()
+    for k, v in sd1.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf.startswith(("running_mean", "running_var")):
+            assert model_cases.rel(live[k], v) < 2e-3, k
+        elif leaf == "num_batches_tracked":
+            assert int(live[k]) == int(v) == 1 + passes, k
+
+
 def test_no_grad_and_determinism():
     m = model_cases.seeded_model().to(DEV).train()
     x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)

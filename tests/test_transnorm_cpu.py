@@ -187,18 +187,31 @@ def test_halves_too_small_raise_like_the_reference():
         deeplab_ref.deeplab_forward(sd, torch.randn(3, 3, 64, 64), training=True)
 
 
-def test_mc_passes_run_as_plain_forwards_under_transnorm():
-    """The repeated batch x.repeat(2) is split into its two copies of x (not into the halves of x), so the fast path of the
-    plain-BN model does not apply: logits equal the oracle's plain stochastic forwards on the repeated batch."""
-    B, S = 4, 64
+def test_mc_fast_path_under_transnorm_equals_plain_stochastic_forwards():
+    """The repeated batch x.repeat(2) is split into its two copies of x (not into the halves of x): identical statistics,
+    alpha = 1, every deterministic layer scaled by exactly 2.  The fast path runs that deterministic part ONCE on x
+    (forward(repeat_prefix=True)) and only the dropout-dependent tail per pass; logits, all four running buffers of every layer
+    and num_batches_tracked must equal the oracle's plain stochastic forwards on the repeated batch."""
+    B, S, passes = 4, 64, 2
     gen = torch.Generator().manual_seed(8)
     x = torch.randn(B, 3, S, S, generator=gen)
     m = _tn_model().train()
     m.set_dropout_masks(deeplab_ref.draw_masks(B, S, S, gen))
     m(x)
     sd1 = deeplab_ref.canonical_state(m.state_dict())
-    mk = [deeplab_ref.draw_masks(2 * B, S, S, gen)]
-    preds = m.mc_dropout_logits(x, passes=1, reps=2, masks=mk)
+    mk = [deeplab_ref.draw_masks(2 * B, S, S, gen) for _ in range(passes)]
+    preds = m.mc_dropout_logits(x, passes=passes, reps=2, masks=mk)
     with torch.no_grad():
-        ref = deeplab_ref.deeplab_forward(sd1, x.repeat(2, 1, 1, 1), training=True, masks=mk[0])[0]
-    assert _rel(preds, ref) < 2e-4
+        ref = torch.cat([deeplab_ref.deeplab_forward(sd1, x.repeat(2, 1, 1, 1), training=True, masks=mk[ps])[0]
+                         for ps in range(passes)], 0)
+    assert preds.shape == ref.shape and _rel(preds, ref) < 2e-4
+    live = m.state_dict()
+    n_buf = 0
+    for k, v in sd1.items():                         # sd1 now holds the oracle's state after the passes
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf.startswith(("running_mean", "running_var")):
+            assert _rel(live[k], v) < 2e-4, k
+            n_buf += 1
+        elif leaf == "num_batches_tracked":
+            assert int(live[k]) == int(v) == 1 + passes, k
+    assert n_buf == 4 * 61

@@ -86,7 +86,7 @@ class _Arena:
 
 
 class _Ctx:
-    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt", "bnlog")
+    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt", "bnlog", "tn_repeat")
 
     def __init__(self):
         self.S = {}
@@ -94,6 +94,7 @@ class _Ctx:
         self.arena = None
         self.nbt = []
         self.bnlog = []          # (prefix, BNRec) of every training-mode BN of this forward
+        self.tn_repeat = False   # TransNorm on a batch that is x repeated twice: both halves ARE x (see forward(repeat_prefix=True))
 
 
 def resnet_plan(output_stride: int = 16, layers=(3, 4, 23)):
@@ -161,7 +162,11 @@ class GeneratorEngine:
         return self._empty(x, P, round4(C))[:, :C]
 
     def _stats(self, ctx, C, training):
-        return ctx.arena.take(2, C, 2 if self.tn else 1) if training else None
+        return ctx.arena.take(2, C, 2 if self._split(ctx) else 1) if training else None
+
+    def _split(self, ctx):
+        """True when a training batch is normalised per domain half with DIFFERENT statistics (TransNorm on a genuine batch)."""
+        return self.tn and not ctx.tn_repeat
 
     def _w(self, ctx, key, kind):
         """Kernel-side layout of a weight, built once per forward context.  (Not cached across forwards: the fused
@@ -185,11 +190,11 @@ class GeneratorEngine:
         return ctx.w_cache[ck]
 
     def _bn(self, ctx, prefix, stats, count, training, scale, shift, mean=None, invstd=None,
-            q1=False) -> Optional[BNRec]:
+            q1=False, N=None) -> Optional[BNRec]:
         p = ctx.params
         g, b = p[prefix + ".weight"], p[prefix + ".bias"]
         if self.tn:
-            return self._tn(ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1)
+            return self._tn(ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1, ctx.N if N is None else N)
         rm, rv = p[prefix + ".running_mean"], p[prefix + ".running_var"]
         if training:
             if count <= 1:
@@ -205,7 +210,7 @@ class GeneratorEngine:
         self.K.bn_eval_coeffs(g, b, rm, rv, BN_EPS, scale, shift)
         return None
 
-    def _tn(self, ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1):
+    def _tn(self, ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1, N):
         """TransNorm coefficients.  Training: scale / shift / mean / invstd are [2, C] (row h = domain half h), the
         halves' counts split ``count`` like the images (N//2 first); eval: plain [C] coefficients."""
         p, K = ctx.params, self.K
@@ -215,7 +220,18 @@ class GeneratorEngine:
         if not training:
             K.tn_eval_coeffs(g, b, rms, rvs, rmt, rvt, BN_EPS, scale, shift)
             return None
-        N = ctx.N
+        if ctx.tn_repeat:
+            # the batch is x repeated twice, so both halves have x's statistics: distance 0, alpha = 1, every channel scaled
+            # by exactly 2.  Plain coefficients over x, doubled; the running buffers of both domains get their updates from
+            # mc_forward's replay (one per stochastic pass), not from this prefix forward.
+            if count <= 1:
+                raise ValueError("Expected more than 1 value per channel when training (%s)" % prefix)
+            K.bn_finalize(stats, float(count), g, b, rms.clone(), rvs.clone(), BN_MOMENTUM, BN_EPS, scale, shift, mean, invstd)
+            scale.mul_(2.0)
+            shift.mul_(2.0)
+            rec = BNRec(prefix, mean, invstd, float(count), q1)
+            ctx.bnlog.append((prefix, rec))
+            return rec
         n0 = N // 2
         per_image = count // N
         counts = (float(n0 * per_image), float((N - n0) * per_image))
@@ -231,17 +247,17 @@ class GeneratorEngine:
         ctx.bnlog.append((prefix, rec))
         return rec
 
-    def _coef(self, x, C, training):
+    def _coef(self, ctx, x, C, training):
         """[4, C] (scale, shift, mean, invstd), or [4, 2, C] when a training batch is normalised per domain half."""
-        return self._empty(x, 4, 2, C) if (self.tn and training) else self._empty(x, 4, C)
+        return self._empty(x, 4, 2, C) if (self._split(ctx) and training) else self._empty(x, 4, C)
 
     def _bn_act(self, ctx, prefix, y, N, H, W, stats, count, training, act, mask=None,
                 mask_scale=1.0, q1=False) -> Act:
         C = y.shape[1]
-        coef = self._coef(y, C, training)
-        rec = self._bn(ctx, prefix, stats, count, training, coef[0], coef[1], coef[2], coef[3], q1)
+        coef = self._coef(ctx, y, C, training)
+        rec = self._bn(ctx, prefix, stats, count, training, coef[0], coef[1], coef[2], coef[3], q1, N)
         return Act(y, N, H, W, coef[0], coef[1], act, mask, mask_scale, rec,
-                   split=N // 2 if (self.tn and training) else 0)
+                   split=N // 2 if (self._split(ctx) and training) else 0)
 
     def _mask(self, x, name, P, C, N, H, W, training, masks):
         if not training:
@@ -491,9 +507,13 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, params: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
-                need_grad: bool, masks=None):
+                need_grad: bool, masks=None, repeat_prefix: bool = False):
+        """``repeat_prefix`` (TransNorm only): run the deterministic part of the network (up to the ASPP output before its
+        dropout and the decoder's low-level branch) as it comes out for the batch ``x.repeat(2, 1, 1, 1)`` - both TransNorm halves
+        are x - without touching running statistics; returns (None, ctx) for ``mc_forward``."""
         K = self.K
         ctx = _Ctx()
+        ctx.tn_repeat = bool(repeat_prefix and self.tn)
         ctx.params, ctx.x = params, x
         S = ctx.S
         N, _, Hin, Win = x.shape
@@ -502,6 +522,8 @@ class GeneratorEngine:
         ctx.N = N
         if training:
             ctx.arena = _Arena(x, STAT_SLOTS * 2 * self.bn_channels * (2 if self.tn else 1))
+        if ctx.tn_repeat and not training:
+            raise ValueError("repeat_prefix describes a training-mode (batch statistics) forward")
         if self.backbone == "mobilenet":
             a, low = self._mobilenet_forward(ctx, x, training)
         else:
@@ -510,8 +532,8 @@ class GeneratorEngine:
         a17, H16, W16 = a, a.H, a.W
         P16 = N * H16 * W16
         cat = self._empty(x, P16, 1280)
-        coef = self._coef(x, 1280, training)        # channel windows below: coef[q][..., sl]
-        split = N // 2 if (self.tn and training) else 0
+        coef = self._coef(ctx, x, 1280, training)   # channel windows below: coef[q][..., sl]
+        split = N // 2 if (self._split(ctx) and training) else 0
         brecs = []
         for j, dl in enumerate(self.dils, start=1):
             sl = slice(256 * (j - 1), 256 * j)
@@ -549,6 +571,11 @@ class GeneratorEngine:
         st = self._stats(ctx, 48, training)
         K.conv(low, self._w(ctx, "decoder.conv1.weight", "ohwi"), 1, 1, ylo, stats=st)
         lo = self._bn_act(ctx, "decoder.bn1", ylo, N, H4, W4, st, P4, training, ACT_RELU)
+        if ctx.tn_repeat:
+            S["dec"] = dict(lo=lo, y0=None)
+            ctx.dims = (N, Hin, Win, H16, W16, H4, W4)
+            ctx.arena, ctx.nbt = None, []
+            return None, ctx
         K.bn_apply(lo, xf[:, 256:304], None)
         K.upsample_fwd(feature, N, H16, W16, xf[:, 0:256], H4, W4)
         xbu = Act(xf[:, :304], N, H4, W4)
@@ -611,10 +638,20 @@ class GeneratorEngine:
         fa, lo = A["fa"], D["lo"]
         if out is None:
             out = self._empty(x, passes * N2, 2, Hin, Win)
+        repeated_tn = ctx.tn_repeat           # ctx comes from forward(repeat_prefix=True): its BN records describe x itself
+        if repeated_tn and reps != 2:
+            raise ValueError("the TransNorm fast path needs the batch repeated exactly twice (its halves are the two copies)")
+        ctx.tn_repeat = False                 # the dropout-dependent tail is a genuine TransNorm batch: the two copies differ
+        if D.get("y0") is None:               # low-level part of conv0, shared by all passes and repetitions
+            tmp = self._empty(x, P4, 48)
+            K.bn_apply(lo, tmp, None)
+            D["y0"] = self._empty(x, P4, 256)
+            K.conv(Act(tmp, N, H4, W4), self._w(ctx, "decoder.last_conv_boundary.0.weight", "low_ohwi"), 3, 1, D["y0"])
+            del tmp
         p05 = DROPOUT["aspp.dropout"]
         for ps in range(passes):
             mk = None if masks is None else masks[ps]
-            ctx.arena = _Arena(x, STAT_SLOTS * 2 * (256 + 256 + 305))
+            ctx.arena = _Arena(x, STAT_SLOTS * 2 * (256 + 256 + 305) * (2 if self.tn else 1))
             feature = self._empty(x, reps * P16, 256)
             xf = self._empty(x, reps * P4, 308)
             for r in range(reps):
@@ -643,7 +680,7 @@ class GeneratorEngine:
             K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1, xf[:, 304:305],
                    bias=params["decoder.last_conv_boundary.8.bias"])
             st = self._stats(ctx, 305, True)
-            K.colstats(xf[:, :305], st)
+            K.colstats(xf[:, :305], st, **({"N": N2} if self.tn else {}))
             m, ms = self._mask(x, "decoder.last_conv.2", reps * P4, 305, N2, H4, W4, True, mk)
             sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
             x1b = self._buf(x, reps * P4, 2)
@@ -655,13 +692,16 @@ class GeneratorEngine:
                 ctx.nbt = []
         # running statistics of the reused (deterministic) BNs: `passes` more updates on the repeated batch
         stoch = set(self._STOCHASTIC_BN)
-        for prefix, rec in ctx.bnlog:
-            if prefix in stoch:
-                continue
-            K.bn_running_replay(rec.mean, rec.invstd, rec.count * reps, passes, BN_MOMENTUM, BN_EPS,
-                                params[prefix + ".running_mean"], params[prefix + ".running_var"])
-        nbt = [params[p + ".num_batches_tracked"] for p, _ in ctx.bnlog
-               if p not in stoch and (p + ".num_batches_tracked") in params]
+        det = [(prefix, rec) for prefix, rec in ctx.bnlog if prefix not in stoch]
+        for prefix, rec in det:
+            if repeated_tn:      # each TransNorm half is one copy of x: both domains' buffers move towards x's statistics
+                for dom in ("source", "target"):
+                    K.bn_running_replay(rec.mean, rec.invstd, rec.count, passes, BN_MOMENTUM, BN_EPS,
+                                        params[prefix + ".running_mean_" + dom], params[prefix + ".running_var_" + dom])
+            else:
+                K.bn_running_replay(rec.mean, rec.invstd, rec.count * reps, passes, BN_MOMENTUM, BN_EPS,
+                                    params[prefix + ".running_mean"], params[prefix + ".running_var"])
+        nbt = [params[p + ".num_batches_tracked"] for p, _ in det if (p + ".num_batches_tracked") in params]
         if nbt:
             torch._foreach_add_(nbt, passes)
         # drop the per-pass records of the stochastic BNs again (bnlog describes the grad-mode forward)

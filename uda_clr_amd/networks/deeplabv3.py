@@ -111,8 +111,14 @@ class DeepLab(Holder):
         that forward are reused and only the dropout-dependent tail is recomputed
         (``GeneratorEngine.mc_forward``); otherwise the passes run as plain forwards."""
         assert self.training, "stochastic passes need training mode (dropout + batch statistics)"
-        # TransNorm splits the REPEATED batch into its two copies of x (identical statistics, alpha = 1), not into the
-        # halves of x the grad-mode forward saw: nothing of that forward can be reused, the passes run as plain forwards
+        if self.transnorm and reps == 2:
+            # TransNorm splits the REPEATED batch into its two copies of x (identical statistics: alpha = 1, gain 2), not into the
+            # halves of x the grad-mode forward saw: nothing of that forward can be reused, but the deterministic part of the
+            # repeated batch is still one forward of x (GeneratorEngine.forward(repeat_prefix=True)), shared by all passes
+            with torch.no_grad():
+                engine = self._engine_for(x)
+                _, ectx = engine.forward(self._flat_state(), x.contiguous().float(), True, True, None, repeat_prefix=True)
+                return engine.mc_forward(ectx, reps, passes, masks=masks)
         for ptr, shape, ectx in ([] if self.transnorm else self._recent):
             if ptr == x.data_ptr() and shape == tuple(x.shape):
                 with torch.no_grad():

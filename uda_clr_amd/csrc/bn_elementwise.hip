@@ -10,6 +10,7 @@
 // Reductions are two-stage and deterministic: per-workgroup fp32 partials, then an fp64 sum.
 // Thread mapping: cg = tid % G float4 channel groups, pl = tid / G pixel lanes (coalesced rows).
 #include "common.h"
+#include <stdlib.h>
 
 int uda_reduce_partials(const float* part, int nrows, int ncols, double* out, hipStream_t st);
 
@@ -346,7 +347,9 @@ struct RedArgs {
     double* out;         // [UDA_STAT_SLOTS][nq][C], fp64 atomics
 };
 
-template <int MODE>
+// ITER: pixel strips per workgroup.  32 for the large layers (fewest atomics); 8 when 32 would leave fewer than ~2 workgroups per
+// CU (the 32x32-map layers at B = 16: a workgroup then walks 256 rows with 8 pixel lanes - latency-bound on an under-filled chip)
+template <int MODE, int ITER>
 __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
     __shared__ float red[3 * 1024];
     const int cblk0 = blockIdx.y * RED_CBLK_SUM;
@@ -371,9 +374,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
             is[j] = ok ? a.invstd[c0 + j] : 0.f;
         }
     }
-    const int64_t base = (int64_t)blockIdx.x * (PP * RED_ITER);
+    const int64_t base = (int64_t)blockIdx.x * (PP * ITER);
 #pragma unroll 4
-    for (int it = 0; it < RED_ITER; ++it) {
+    for (int it = 0; it < ITER; ++it) {
         const int64_t p = base + (int64_t)it * PP + pl;
         if (!active || p >= a.P) continue;
         const float4 xv = uda_ld4(a.x + p * a.ldx + c0);
@@ -418,10 +421,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
     }
 }
 
-static inline int red_nwg(int64_t P, int C) {
+static inline int red_nwg(int64_t P, int C, int iter) {
     const int Cb = C < RED_CBLK_SUM ? C : RED_CBLK_SUM;
     const int PP = 256 / ((Cb + 3) / 4);
-    return uda_cdiv(P, (int64_t)PP * RED_ITER);
+    return uda_cdiv(P, (int64_t)PP * iter);
+}
+static inline bool red_short(int64_t P, int C) {
+    static const int thr = getenv("UDA_RED_SHORT_WGS") ? atoi(getenv("UDA_RED_SHORT_WGS")) : 512;
+    return (int64_t)red_nwg(P, C, RED_ITER) * uda_cdiv(C, RED_CBLK_SUM) < thr;
 }
 
 extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, void* stream) {
@@ -430,8 +437,10 @@ extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int n
                 "uda_colstats: bad args");
     RedArgs a;
     a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.out = out;
-    const int nwg = red_nwg(P, C);
-    hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nwg, uda_cdiv(C, RED_CBLK_SUM)), dim3(256), 0, st, a);
+    if (red_short(P, C))
+        hipLaunchKernelGGL((colreduce_kernel<0, 8>), dim3(red_nwg(P, C, 8), uda_cdiv(C, RED_CBLK_SUM)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((colreduce_kernel<0, RED_ITER>), dim3(red_nwg(P, C, RED_ITER), uda_cdiv(C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("colstats");
     return 0;
 }
@@ -445,8 +454,10 @@ extern "C" int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y
     const int64_t P = (int64_t)y->N * y->H * y->W;
     RedArgs a;
     a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.out = sums;
-    const int nwg = red_nwg(P, y->C);
-    hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nwg, uda_cdiv(y->C, RED_CBLK_SUM)), dim3(256), 0, st, a);
+    if (red_short(P, y->C))
+        hipLaunchKernelGGL((colreduce_kernel<1, 8>), dim3(red_nwg(P, y->C, 8), uda_cdiv(y->C, RED_CBLK_SUM)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((colreduce_kernel<1, RED_ITER>), dim3(red_nwg(P, y->C, RED_ITER), uda_cdiv(y->C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("bnbwd_reduce");
     return 0;
 }

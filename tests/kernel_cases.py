@@ -402,6 +402,9 @@ CASES = [
     ("conv3x3 320->256 dil6", case_conv(2, 8, 8, 320, 256, 3, 6, lazy=False)),
     ("conv3x3 320->256 dil12 (mostly padding)", case_conv(2, 8, 8, 320, 256, 3, 12, lazy=False)),
     ("conv3x3 64->40 dil2 odd sizes", case_conv(1, 11, 9, 64, 40, 3, 2)),
+    ("conv3x3 256->48 (long K, narrow tile)", case_conv(2, 16, 16, 256, 48, 3, 1, lazy=False)),
+    ("conv3x3 128->64 relu mask stats (long K, narrow tile)", case_conv(2, 12, 12, 128, 64, 3, 1, mask=True)),
+    ("dgrad3x3 48<-256 addend (the decoder's low-level input gradient)", case_dgrad(2, 16, 16, 48, 256, 3, 1, accumulate=True)),
     # dgrad through the same kernel
     ("dgrad1x1 96<-16", case_dgrad(2, 12, 12, 96, 16, 1, 1)),
     ("dgrad1x1 305<-2", case_dgrad(2, 16, 16, 305, 2, 1, 1)),

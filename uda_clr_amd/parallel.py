@@ -35,11 +35,12 @@ class FlatGradAllReduce:
         torch._foreach_copy_(self.views, grads)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(w)
+        have = [(p.grad, v) for p, v in zip(self.params, self.views) if p.grad is not None]
+        if have:                                   # one multi-tensor copy instead of a launch per parameter
+            torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
 
 
 class AllReduceSum(torch.autograd.Function):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   bash profiles/run_profiles.sh <out-dir under gpurun_out/> [pf|so|rn|pmc ...]
+#   bash profiles/run_profiles.sh <out-dir under gpurun_out/> [pf|so|rn|tn|pmc ...]
 # kernel-trace/stats runs and PMC runs are separate rocprofv3 invocations (never combined), program directly after `--`.
 set -o pipefail
 OUT=${1:-gpurun_out/prof}; shift
@@ -12,6 +12,7 @@ for w in $WHAT; do
     pf) ARGS="--steps 5 --warmup 2 --no-cpu-baseline"; PER=2 ;;
     so) ARGS="--workload source_only --steps 5 --warmup 2 --no-cpu-baseline"; PER=1 ;;
     rn) ARGS="--backbone resnet --workload source_only --batch 8 --steps 5 --warmup 2 --no-cpu-baseline"; PER=1 ;;
+    tn) ARGS="--use-tn --steps 5 --warmup 2 --no-cpu-baseline"; PER=5 ;;       # 2 halves x (2 grad-mode forwards) + the MC prefix forward
     pmc)
       rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/f.log 2>&1 || exit 1
       rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/w.log 2>&1 || exit 1

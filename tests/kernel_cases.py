@@ -924,6 +924,9 @@ CASES += [
     ("upconv fwd/bwd 2 x (16x16 -> 32x32) x 32 (x2: 4-column strips)", case_upconv(2, 16, 16, 32, 32, 32)),
     ("upconv fwd/bwd 1 x (5x7 -> 13x18) x 8 (W % 4 != 0: pixel kernel), addend", case_upconv(1, 5, 7, 13, 18, 8, addend_rows=234)),
     ("upconv fwd/bwd 2 x (1x1 -> 4x4) x 4 (degenerate source)", case_upconv(2, 1, 1, 4, 4, 4)),
+    ("upconv fwd/bwd 1 x (43x43 -> 128x128) x 8 (scale exactly 1/3: 4-column strips)", case_upconv(1, 43, 43, 128, 128, 8)),
+    ("upconv fwd/bwd 1 x (85x85 -> 128x128) x 8 (scale 0.661: 4-column strips)", case_upconv(1, 85, 85, 128, 128, 8)),
+    ("upconv fwd/bwd 1 x (86x86 -> 128x128) x 8 (scale 0.669: pixel kernel)", case_upconv(1, 86, 86, 128, 128, 8)),
     ("upconv fwd/bwd 3 x (32x32 -> 128x128) x 256 (the decoder's shape)", case_upconv(3, 32, 32, 128, 128, 256, addend_rows=16384)),
     ("upconv identity vs interpolate+conv2d 2 x (8x8 -> 32x32), 64+16 -> 32", case_upconv_identity(2, 8, 8, 32, 32, 64, 16, 32)),
 ]

@@ -649,11 +649,14 @@ class GeneratorEngine:
             K.conv(Act(tmp, N, H4, W4), self._w(ctx, "decoder.last_conv_boundary.0.weight", "low_ohwi"), 3, 1, D["y0"])
             del tmp
         p05 = DROPOUT["aspp.dropout"]
+        # one x_feature buffer for all passes: its 48 low-level channels do not depend on a dropout mask and are written once
+        xf = self._empty(x, reps * P4, 308)
+        for r in range(reps):
+            K.bn_apply(lo, xf[r * P4:(r + 1) * P4, 256:304], None)
         for ps in range(passes):
             mk = None if masks is None else masks[ps]
             ctx.arena = _Arena(x, STAT_SLOTS * 2 * (256 + 256 + 305) * (2 if self.tn else 1))
             feature = self._empty(x, reps * P16, 256)
-            xf = self._empty(x, reps * P4, 308)
             for r in range(reps):
                 m = torch.empty((P16, 256), dtype=torch.uint8, device=x.device)
                 if mk is not None:
@@ -663,7 +666,6 @@ class GeneratorEngine:
                     self.rng_offset += 1
                 K.bn_apply(Act(fa.x, N, H16, W16, fa.scale, fa.shift, ACT_RELU, m, 1.0 / (1.0 - p05)),
                            feature[r * P16:(r + 1) * P16], None)
-                K.bn_apply(lo, xf[r * P4:(r + 1) * P4, 256:304], None)
             K.upsample_fwd(feature, N2, H16, W16, xf[:, 0:256], H4, W4)
             xbu = Act(xf[:, :304], N2, H4, W4)
             yb1 = self._empty(x, reps * P4, 256)

@@ -40,3 +40,15 @@ opt.zero_grad(set_to_none=True)
 o = model(img); l = ops.seg_loss(o[0], o[1], tmap, tbd); l.backward()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("generator fwd+bwd (B=16): host enqueue %.1f ms, GPU done after %.1f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+# memory stability over many iterations of the full step (no growth expected: contexts are released by backward / _forget)
+for prm in model.parameters():
+    prm.requires_grad_(True)
+torch.cuda.reset_peak_memory_stats()
+marks = []
+for it in range(40):
+    tr.train_step(sS, sT)
+    if it in (4, 39):
+        torch.cuda.synchronize()
+        marks.append((it, torch.cuda.memory_allocated() / 2**30, torch.cuda.max_memory_allocated() / 2**30, torch.cuda.memory_reserved() / 2**30))
+for m in marks:
+    print("after step %d: allocated %.2f GiB, peak %.2f GiB, reserved %.2f GiB" % m)

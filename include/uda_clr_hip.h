@@ -273,6 +273,17 @@ int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, int C, int 
 int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W, int C, int dil, float* dg, int64_t ldg, int h, int w,
                    void* stream);
 
+/* ---- evaluation post-processing of the predicted probability maps (utils/Utils.py:427-463: postprocessing +
+ * get_largest_fillhole), per image and channel (0 cup, 1 disc): threshold -> 5 x 7x7 median (zero padded) -> erosion by the
+ * L1 ball of radius 7 (outside = set, skimage's convention) -> largest 8-connected component (first maximum in raster order of
+ * the components' first pixels) -> holes filled (background not 4-connected to the border).
+ * pred f32 [B,2,H,W] -> out uint8 [B,2,H,W] in {0,1}.  sweeps: launches of each of the two tile-wise propagations (a launch
+ * carries labels across whole 32x32 tiles); not_converged: DEVICE int[2], set to the number of tiles an extra sweep still
+ * changed (components, flood) - 0 means the result is final, otherwise call again with more sweeps. */
+size_t uda_postprocess_workspace_bytes(int B, int H, int W);
+int uda_postprocess(const float* pred, int B, int H, int W, float thr_cup, float thr_disc, int sweeps, uint8_t* out,
+                    int* not_converged, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- device-side tail of the input pipeline.  The reference's dataloader workers run these per sample
  * on the CPU with scipy.ndimage; here they run per uint8 BATCH on the GPU, bit-identical to the scipy calls.
  * uda_normalize_tf: dataloaders/custom_transforms.py:432-466 (Normalize_tf), :414-429 (GetBoundary), :504-507 (ToTensor).

@@ -930,3 +930,65 @@ CASES += [
     ("upconv fwd/bwd 3 x (32x32 -> 128x128) x 256 (the decoder's shape)", case_upconv(3, 32, 32, 128, 128, 256, addend_rows=16384)),
     ("upconv identity vs interpolate+conv2d 2 x (8x8 -> 32x32), 64+16 -> 32", case_upconv_identity(2, 8, 8, 32, 32, 64, 16, 32)),
 ]
+
+
+# ---------------------------------------------------------------- evaluation post-processing vs scipy
+def _scipy_postprocess(prob, thr_cup, thr_disc):
+    """utils/Utils.py:427-463 with skimage's two calls replaced by their scipy.ndimage equivalents: binary_erosion(diamond(7))
+    = ndimage.binary_erosion(structure=L1 ball, border_value=1) (skimage erodes with the outside set), measure.label =
+    ndimage.label with the full 3x3 structure (both number components in raster order of their first pixel)."""
+    import numpy as np
+    import scipy.signal
+    from scipy import ndimage
+    yy, xx = np.mgrid[-7:8, -7:8]
+    diamond = (np.abs(yy) + np.abs(xx)) <= 7
+    out = np.zeros(prob.shape, np.uint8)
+    for c, thr in ((0, thr_cup), (1, thr_disc)):
+        m = (prob[c] > thr).astype(np.uint8)
+        for _ in range(5):
+            m = scipy.signal.medfilt2d(m, 7)
+        m = ndimage.binary_erosion(m, structure=diamond, border_value=1).astype(np.uint8)
+        lab, n = ndimage.label(m, structure=np.ones((3, 3)))
+        if n:
+            areas = np.bincount(lab.ravel())[1:]
+            m[lab != int(np.argmax(areas)) + 1] = 0
+        out[c] = ndimage.binary_fill_holes(m.astype(int)).astype(np.uint8)
+    return out
+
+
+def case_postprocess(B, H, W, seed=61):
+    def run(dev):
+        import numpy as np
+        g = gen(seed)
+        K = hip()
+        rs = np.random.RandomState(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=g)))
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        prob = np.zeros((B, 2, H, W), np.float32)
+        for b in range(B):
+            for c in range(2):
+                p = 0.08 * rs.rand(H, W)
+                for _ in range(rs.randint(1, 4)):               # a few blobs (one of them touching the border in sample 0), with holes
+                    cy = (0.05 if (b == 0 and c == 1) else rs.uniform(0.25, 0.75)) * H
+                    cx, a, d = rs.uniform(0.25, 0.75) * W, rs.uniform(0.12, 0.3) * H, rs.uniform(0.12, 0.3) * W
+                    r = np.sqrt(((yy - cy) / a) ** 2 + ((xx - cx) / d) ** 2)
+                    p = np.maximum(p, np.clip(1.25 - r, 0, 1))
+                    hole = np.sqrt((yy - cy - 0.3 * a) ** 2 + (xx - cx) ** 2) < rs.uniform(2, 9)
+                    p[hole] = 0.02
+                p += 0.5 * (rs.rand(H, W) < 0.03)                 # salt: isolated pixels the median removes
+                p[rs.rand(H, W) < 0.03] = 0.0                     # pepper inside the blobs
+                prob[b, c] = np.clip(p, 0, 1)
+        out = K.postprocess(torch.from_numpy(prob).to(dev), 0.75, 0.75).cpu().numpy()
+        bad = sum(int((out[b] != _scipy_postprocess(prob[b], 0.75, 0.75)).sum()) for b in range(B))
+        outd = K.postprocess(torch.from_numpy(prob[:1]).to(dev), 0.1, 0.5).cpu().numpy()
+        bad += int((outd[0] != _scipy_postprocess(prob[0], 0.1, 0.5)).sum())
+        empty = K.postprocess(torch.zeros(1, 2, H, W, device=dev), 0.75, 0.75)
+        bad += int(empty.sum())
+        return float(bad), 0.5                  # bit-exact or fail
+    return run
+
+
+CASES += [
+    ("postprocess 3 x 2 x 128 x 128 vs scipy (bit-exact)", case_postprocess(3, 128, 128)),
+    ("postprocess 2 x 2 x 200 x 136 vs scipy (ragged tiles)", case_postprocess(2, 200, 136, seed=62)),
+    ("postprocess 1 x 2 x 512 x 512 vs scipy", case_postprocess(1, 512, 512, seed=63)),
+]

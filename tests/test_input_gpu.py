@@ -104,3 +104,22 @@ def test_level2_decode_on_the_device_equals_the_cpu_chain(tmp_path, monkeypatch)
     assert not torch.equal(dec2["image"][0], dec["image"][0])
     assert float(dec2["image"].min()) >= -1.0 and float(dec2["image"].max()) <= 1.0
     assert bool((dec2["map"][:, 0] <= dec2["map"][:, 1]).all())
+
+
+def test_utils_postprocessing_dropin_matches_scipy_and_the_reference_return_types():
+    """utils.Utils.postprocessing (Utils.py:438-463): one [2,H,W] probability map -> numpy masks; uint8 for the default branch,
+    float (a copy of the probabilities overwritten by the masks) for dataset names starting with 'D'."""
+    from kernel_cases import _scipy_postprocess
+    from uda_clr_amd.utils import Utils
+    rs = np.random.RandomState(3)
+    yy, xx = np.meshgrid(np.arange(160), np.arange(160), indexing="ij")
+    prob = np.stack([np.clip(1.3 - np.sqrt(((yy - 80) / r) ** 2 + ((xx - 70) / (r * 1.2)) ** 2), 0, 1) for r in (30.0, 55.0)]).astype(np.float32)
+    prob = np.clip(prob + 0.3 * (rs.rand(2, 160, 160) < 0.02), 0, 1).astype(np.float32)
+    out = Utils.postprocessing(torch.from_numpy(prob), threshold=0.75, dataset='G')
+    assert out.dtype == np.uint8 and out.shape == (2, 160, 160)
+    assert np.array_equal(out, _scipy_postprocess(prob, 0.75, 0.75))
+    outd = Utils.postprocessing(torch.from_numpy(prob), dataset='Drishti-GS')
+    assert outd.dtype == np.float32 and np.array_equal(outd.astype(np.uint8), _scipy_postprocess(prob, 0.1, 0.5))
+    batch = Utils.postprocessing_batch(torch.from_numpy(np.stack([prob, prob[:, ::-1].copy()])).to(DEV))
+    assert batch.shape == (2, 2, 160, 160) and np.array_equal(batch[0].cpu().numpy(), out)
+    assert np.array_equal(batch[1].cpu().numpy(), _scipy_postprocess(prob[:, ::-1].copy(), 0.75, 0.75))

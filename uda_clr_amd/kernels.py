@@ -100,6 +100,8 @@ SYMBOLS = {
     "uda_upconv_fused_stats": (_I, [_I, _I, _I, _I, _I, _I]),
     "uda_upconv_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P, _P]),
     "uda_upconv_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
+    "uda_postprocess_workspace_bytes": (_U, [_I, _I, _I]),
+    "uda_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _U, _P]),
     "uda_normalize_tf_workspace_bytes": (_U, [_I, _I, _I]),
     "uda_normalize_tf": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _P, _P, _U, _P]),
     "uda_field_smooth": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _P, _P]),
@@ -721,6 +723,25 @@ class HipKernels:
                                              sp_value.data_ptr(), sp_pos.shape[1], lut.data_ptr(), erase_box.data_ptr(),
                                              self._stream()))
         return image_u8
+
+    def postprocess(self, pred, thr_cup, thr_disc, sweeps=None):
+        """pred f32 [B,2,H,W] probabilities -> uint8 [B,2,H,W] masks after the reference's evaluation post-processing.
+        Runs the tile-wise propagations for ``sweeps`` launches (default: enough for any shape whose geodesic paths cross each
+        tile row / column at most twice) and repeats with twice as many while the device reports unfinished tiles."""
+        self._dev(pred)
+        assert pred.dtype == torch.float32 and pred.is_contiguous() and pred.dim() == 4 and pred.shape[1] == 2
+        B, _, H, W = pred.shape
+        out = torch.empty(B, 2, H, W, dtype=torch.uint8, device=pred.device)
+        flags = torch.zeros(2, dtype=torch.int32, device=pred.device)
+        ws = self._ws(pred, self.lib.uda_postprocess_workspace_bytes(B, H, W))
+        n = int(sweeps) if sweeps else 2 * ((H + 31) // 32 + (W + 31) // 32) + 4
+        for _ in range(6):
+            self._ck(self.lib.uda_postprocess(pred.data_ptr(), B, H, W, float(thr_cup), float(thr_disc), n, out.data_ptr(),
+                                              flags.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+            if int(flags.sum()) == 0:            # host sync: evaluation path only
+                return out
+            n *= 2
+        raise UdaError("uda_postprocess: label propagation did not converge after %d sweeps" % n)
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
         for t in (params, grads, exp_avg, exp_avg_sq):

@@ -5,8 +5,10 @@
   gen_prototype_retrify(oT_before, xt_feature, preds, features, T, stride)   Utils.py:159-225
   sigmoid_rampup / linear_rampup / cosine_rampdown               Utils.py:312-334
 
-Visualisation / post-processing helpers of the reference (Utils.py:349-590) are outside the hot
-path and not built.
+  postprocessing(prediction, threshold=0.75, dataset='G')         Utils.py:438-463 (+ get_largest_fillhole :427-436)
+
+The visualisation helpers of the reference (Utils.py:349-426, 466-590) are outside the hot path and not built
+(SURVEY.md section 2).
 """
 import math
 
@@ -37,3 +39,31 @@ def cosine_rampdown(current, rampdown_length):
 
 def adaptation_factor(m):
     return 1.0 / (1.0 + math.exp(-0.8 * (m + 1))) - 0.3
+
+
+def postprocessing(prediction, threshold=0.75, dataset='G'):
+    """Evaluation post-processing of ONE image's [2, H, W] (cup, disc) probability map, as utils/Utils.py:438-463: threshold
+    (dataset names starting with 'D': disc > 0.5, cup > 0.1; otherwise both > ``threshold``), five 7x7 median filters, erosion
+    by the radius-7 diamond, largest connected component, holes filled.  Runs on the device (``uda_postprocess``); a CPU
+    tensor is moved there.  Returns a numpy array like the reference's: [2, H, W], float for the 'D' branch (it writes the
+    masks into a copy of the probabilities), uint8 otherwise.  ``postprocessing_batch`` does a whole [B, 2, H, W] batch."""
+    import torch
+    from ..ops import kernels
+    pred = torch.as_tensor(prediction)
+    if pred.dim() != 3 or pred.shape[0] != 2:
+        raise ValueError("expected a [2, H, W] prediction")
+    out = postprocessing_batch(pred[None], threshold, dataset)[0].cpu().numpy()
+    return out.astype(np.float32) if dataset[0] == 'D' else out
+
+
+def postprocessing_batch(predictions, threshold=0.75, dataset='G'):
+    """[B, 2, H, W] probabilities -> uint8 [B, 2, H, W] post-processed masks, on the device."""
+    import torch
+    from ..ops import kernels
+    pred = predictions
+    if not pred.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError("uda_clr_amd post-processing computes only on the MI355X HIP kernels (there is no CPU fallback)")
+        pred = pred.cuda()
+    thr_cup, thr_disc = (0.1, 0.5) if dataset[0] == 'D' else (threshold, threshold)
+    return kernels().postprocess(pred.contiguous().float(), thr_cup, thr_disc)

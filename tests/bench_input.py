@@ -76,3 +76,24 @@ for b in range(n):
 t_el = (time.perf_counter() - t0) / n
 print("CPU (1 core, scipy): Normalize_tf+ToTensor %.1f ms/sample = %.1f samples/s; elastic_transform %.1f ms/sample = %.1f samples/s"
       % (t_ntf * 1e3, 1 / t_ntf, t_el * 1e3, 1 / t_el))
+
+# evaluation post-processing: device batch vs scipy per image on one core
+from kernel_cases import _scipy_postprocess
+rs = np.random.RandomState(5)
+yy, xx = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+pb = np.stack([np.stack([np.clip(1.3 - np.sqrt(((yy - 256) / r) ** 2 + ((xx - 240) / (1.2 * r)) ** 2), 0, 1) for r in (90.0, 170.0)]) for _ in range(16)]).astype(np.float32)
+pb = np.clip(pb + 0.5 * (rs.rand(*pb.shape) < 0.02), 0, 1).astype(np.float32)
+pd = torch.from_numpy(pb).to(dev)
+K.postprocess(pd, 0.75, 0.75)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    K.postprocess(pd, 0.75, 0.75)
+torch.cuda.synchronize()
+t_dev = (time.perf_counter() - t0) / 5
+t0 = time.perf_counter()
+for b in range(2):
+    _scipy_postprocess(pb[b], 0.75, 0.75)
+t_cpu = (time.perf_counter() - t0) / 2
+print("postprocess       B=16 512x512    %7.3f ms per batch (incl. the convergence read-back) = %.0f images/s;  scipy on one core %.1f ms/image = %.1f images/s"
+      % (t_dev * 1e3, 16 / t_dev, t_cpu * 1e3, 1 / t_cpu))

@@ -227,6 +227,18 @@ def make_proto():
         for i, (r, o) in enumerate(zip(ref, mine)):
             out["gp.%s.%d" % (tag, i)] = r.reshape(-1).numpy()
             check("gen_prototype %s %d" % (tag, i), o, r, 1e-6)
+    # soft branch with gradient into the prediction (Trainer_prototype_full.py:375-377, quirk Q6): seeded cotangents
+    v = torch.randn(4, C, generator=g)
+    for tag, fn in (("ref", gen_prototype), ("mine", proto_ref.gen_prototype)):
+        sp, ft = soft.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        sum((c.reshape(-1) * v[i]).sum() for i, c in enumerate(fn(sp, ft))).backward()
+        if tag == "ref":
+            d_pred, d_feat = sp.grad, ft.grad
+            summarize("gp.soft.d_pred", d_pred, out)
+            summarize("gp.soft.d_feat", d_feat, out)
+        else:
+            check("gen_prototype soft d_pred", sp.grad, d_pred, 1e-5)
+            check("gen_prototype soft d_feat", ft.grad, d_feat, 1e-5)
     out["gp.seed"] = 21
     # gen_prototype_retrify: hard-coded 305 x 128 x 128 and 512^2 predictions (quirk Q7)
     g = torch.Generator().manual_seed(22)

@@ -295,18 +295,19 @@ size_t uda_normalize_tf_workspace_bytes(int B, int H, int W);
 int uda_normalize_tf(const uint8_t* image_hwc, const uint8_t* label, int B, int H, int W, const double* gauss_w, int radius,
                      float* image, float* map, float* boundary, void* workspace, size_t workspace_bytes, void* stream);
 /* custom_transforms.py:95-147 (elastic_transform).  uda_field_smooth: out = alpha * gaussian_filter(noise, sigma,
- * mode='constant') on [B,H,W] float planes (weights_dev: DEVICE pointer to radius+1 doubles, centre first; tmp: [B,H,W]).
+ * mode='constant') on [B,H,W] float64 planes, in scipy's own summation order (bit-identical to the reference's field;
+ * weights_dev: DEVICE pointer to radius+1 doubles, centre first; tmp: [B,H,W] doubles).
  * uda_elastic_warp: map_coordinates(order=1) of image (mode 'constant', 0 outside) and label (mode 'nearest') at
  * (h + dx, w + dy), rounded to uint8; apply (uint8 [B] or null) = 0 copies a sample through. */
-int uda_field_smooth(const float* noise, int B, int H, int W, const double* weights_dev, int radius, float alpha, float* tmp,
-                     float* out, void* stream);
+int uda_field_smooth(const double* noise, int B, int H, int W, const double* weights_dev, int radius, double alpha, double* tmp,
+                     double* out, void* stream);
 /* custom_transforms.py:150-250 (add_salt_pepper_noise, adjust_light, eraser) on a uint8 batch IN PLACE, in that order, with the
  * per-sample parameters the dataloader workers drew: sp_pos int32 [B, sp_max, 2] (row, column), sp_count int32 [B], sp_value
  * int32 [B] (1 salt / 0 pepper, as the reference writes them); lut uint8 [B, 256] (identity when adjust_light did not fire);
  * erase_box int32 [B, 5] = (top, left, height, width, grey level), height 0 = no erasing. */
 int uda_photometric_u8(uint8_t* image_hwc, int B, int H, int W, const int* sp_pos, const int* sp_count, const int* sp_value,
                        int sp_max, const uint8_t* lut, const int* erase_box, void* stream);
-int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const float* dx, const float* dy, const uint8_t* apply,
+int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const double* dx, const double* dy, const uint8_t* apply,
                      int B, int H, int W, uint8_t* image_out, uint8_t* label_out, void* stream);
 
 #ifdef __cplusplus

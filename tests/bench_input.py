@@ -43,14 +43,14 @@ iu, lu = torch.from_numpy(img).to(dev), torch.from_numpy(lab).to(dev)
 px = B * S * S
 ms = timeit(lambda: K.normalize_tf(iu, lu))
 print("normalize_tf      B=%d %dx%d  %7.3f ms  %8.1f samples/s  %7.1f GB/s algorithmic (28 B/px)" % (B, S, S, ms, B / ms * 1e3, 28.0 * px / ms / 1e6))
-noise = torch.rand(2, B, S, S, device=dev) * 2 - 1
+noise = torch.rand(2, B, S, S, device=dev, dtype=torch.float64) * 2 - 1
 ms_f = timeit(lambda: K.field_smooth(noise, 0.08 * S, 2.0 * S))
 fld = K.field_smooth(noise, 0.08 * S, 2.0 * S)
-print("field_smooth      B=%d           %7.3f ms  %8.1f samples/s  %7.1f GB/s algorithmic (32 B/px; radius %d taps per axis)"
-      % (B, ms_f, B / ms_f * 1e3, 32.0 * px / ms_f / 1e6, int(4 * 0.08 * S + 0.5)))
+print("field_smooth      B=%d           %7.3f ms  %8.1f samples/s  %7.1f GB/s algorithmic (64 B/px of float64; radius %d taps per axis)"
+      % (B, ms_f, B / ms_f * 1e3, 64.0 * px / ms_f / 1e6, int(4 * 0.08 * S + 0.5)))
 ap = torch.ones(B, dtype=torch.uint8, device=dev)
 ms_w = timeit(lambda: K.elastic_warp(iu, lu, fld[0], fld[1], ap))
-print("elastic_warp      B=%d           %7.3f ms  %8.1f samples/s  %7.1f GB/s algorithmic (16 B/px)" % (B, ms_w, B / ms_w * 1e3, 16.0 * px / ms_w / 1e6))
+print("elastic_warp      B=%d           %7.3f ms  %8.1f samples/s  %7.1f GB/s algorithmic (24 B/px)" % (B, ms_w, B / ms_w * 1e3, 24.0 * px / ms_w / 1e6))
 # host->device copy of the uint8 batch (pinned), the only PCIe leg of the deferred tail: 4 B/px instead of 24 B/px of floats
 hi, hl = torch.from_numpy(img).pin_memory(), torch.from_numpy(lab).pin_memory()
 ms_c = timeit(lambda: (hi.to(dev, non_blocking=True), hl.to(dev, non_blocking=True)))

@@ -18,6 +18,7 @@ inputs and stores inputs' seeds + expected outputs as small data files:
   proto.npz              gen_prototype / gen_prototype_retrify inputs (by seed) and outputs
   metrics.json           dice_coeff_2label / pixel_acc on seeded logits
   trainer_*.json         loss rows written by the reference's own Trainer loops
+  input_pipeline.json, input_pipeline_small.npz   outputs of the reference's dataloaders/custom_transforms.py on seeded samples
 
 While generating, every fixture is also compared with the oracle restatement (oracle/), so a
 successful run pins the oracle against the reference on full tensors, not only on the samples
@@ -407,10 +408,125 @@ def make_trainer_proto(tmp):
                    "rows": ref_rows}, f)
 
 
+# ----------------------------------------------------------------------------- input pipeline
+def digest(a):
+    import hashlib
+    a = np.ascontiguousarray(a)
+    return "%s%s:%s" % (a.dtype.str, list(a.shape), hashlib.sha256(a.tobytes()).hexdigest())
+
+
+def make_input_pipeline():
+    """The reference's own dataloaders/custom_transforms.py (:22-147 salt-and-pepper / adjust_light / eraser /
+    elastic_transform, :414-466 GetBoundary / Normalize_tf, :496-507 ToTensor) on seeded uint8 samples
+    (tests/make_golden_inputs.fundus_u8).  It needs cv2 only for cv2.LUT (a table lookup, stubbed as table[image]) and the
+    removed alias np.float.  elastic_transform seeds its noise from OS entropy (RandomState(None)): numpy's RandomState is
+    swapped for a seeded one while it runs, so a test can redraw the same uniform fields.  Stores, per case, the seeds and the
+    SHA-256 of every output array (+ the full arrays of the small cases, to locate a mismatching byte)."""
+    import random
+    from PIL import Image
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from make_golden_inputs import fundus_u8
+    sys.modules["cv2"].LUT = lambda img, table: table[img]
+    from dataloaders import custom_transforms as rt
+    meta, small = {}, {}
+
+    def tensors(s):
+        return {k: s[k].numpy() for k in ("image", "map", "boundary")}
+
+    def record(name, arrays, info, keep):
+        meta[name] = dict(info, sha256={k: digest(v) for k, v in arrays.items()})
+        if keep:
+            for k, v in arrays.items():
+                small["%s.%s" % (name, k)] = np.ascontiguousarray(v)
+
+    # ---- Normalize_tf + GetBoundary + ToTensor
+    for tag, (B, H, W, seed) in {"ntf_small": (3, 96, 80, 41), "ntf_512": (2, 512, 512, 42)}.items():
+        img, lab = fundus_u8(B, H, W, seed)
+        for b in range(B):
+            s = rt.ToTensor()(rt.Normalize_tf()({"image": Image.fromarray(img[b]), "label": Image.fromarray(lab[b]), "img_name": "s"}))
+            record("%s.%d" % (tag, b), tensors(s), dict(B=B, H=H, W=W, seed=seed, b=b), H < 128 and b == 0)
+
+    # ---- elastic_transform with a seeded RandomState (fires when random.random() > 0.5)
+    RS = np.random.RandomState
+
+    def fire_seed(want, start):        # a `random` seed whose first draw does / does not fire the transform
+        s = start
+        while (random.Random(s).random() > 0.5) != want:
+            s += 1
+        return s
+    for tag, (B, S, seed) in {"elastic_small": (2, 96, 43), "elastic_512": (1, 512, 44)}.items():
+        img, lab = fundus_u8(B, S, S, seed)
+        for b in range(B):
+            np_seed, py_seed = 1000 + seed + b, fire_seed(True, 10 * seed + b)
+            np.random.RandomState = lambda s=None, _k=np_seed: RS(_k)
+            try:
+                random.seed(py_seed)
+                o = rt.elastic_transform()({"image": Image.fromarray(img[b]), "label": Image.fromarray(lab[b]), "img_name": "s"})
+            finally:
+                np.random.RandomState = RS
+            assert not np.array_equal(o["image"], img[b])
+            record("%s.%d" % (tag, b), {"image": o["image"], "label": o["label"]},
+                   dict(B=B, H=S, W=S, seed=seed, b=b, noise_seed=np_seed, py_seed=py_seed), S < 128 and b == 0)
+
+    # ---- photometric transforms: every branch (salt / pepper / none, gamma / none, erase / none)
+    img, lab = fundus_u8(1, 96, 96, 45)
+    def branch_seeds(pred, n=1, start=0):
+        out, s = [], start
+        while len(out) < n:
+            if pred(random.Random(s).random()):
+                out.append(s)
+            s += 1
+        return out
+    sp_seeds = branch_seeds(lambda r: r > 0.75) + branch_seeds(lambda r: 0.5 < r <= 0.75) + branch_seeds(lambda r: r <= 0.5)
+    for s_ in sp_seeds:
+        random.seed(s_); np.random.seed(s_)
+        o = rt.add_salt_pepper_noise()({"image": img[0].copy(), "label": lab[0], "img_name": "s"})
+        record("salt_pepper.%d" % s_, {"image": o["image"]}, dict(seed=45, py_seed=s_, np_seed=s_), True)
+    for s_ in branch_seeds(lambda r: r > 0.5, 3) + branch_seeds(lambda r: r <= 0.5):
+        random.seed(s_)
+        o = rt.adjust_light()({"image": img[0].copy(), "label": lab[0], "img_name": "s"})
+        record("adjust_light.%d" % s_, {"image": np.asarray(o["image"])}, dict(seed=45, py_seed=s_), True)
+    for s_ in branch_seeds(lambda r: r <= 0.5, 2) + branch_seeds(lambda r: r > 0.5):
+        random.seed(s_); np.random.seed(s_)
+        im = img[0].copy()
+        o = rt.eraser()({"image": im, "label": lab[0], "img_name": "s"})
+        record("eraser.%d" % s_, {"image": np.asarray(o["image"])}, dict(seed=45, py_seed=s_, np_seed=s_), True)
+
+    # ---- the whole array part of the training chain (train_use_fix_initial.py:153-159) with one seed per sample: pins the ORDER
+    # and NUMBER of draws each transform takes from `random` and `np.random`
+    img, lab = fundus_u8(8, 96, 96, 46)
+    fired = set()
+    for b in range(8):
+        np.random.RandomState = lambda s=None, _k=2000 + b: RS(_k)
+        try:
+            random.seed(300 + b); np.random.seed(300 + b)
+            s = {"image": Image.fromarray(img[b]), "label": Image.fromarray(lab[b]), "img_name": "s"}
+            trail = []
+            for t in (rt.elastic_transform(), rt.add_salt_pepper_noise(), rt.adjust_light(), rt.eraser()):
+                before = np.array(s["image"]).copy()
+                s = t(s)
+                trail.append(int(not np.array_equal(before, np.array(s["image"]))))
+            s = rt.ToTensor()(rt.Normalize_tf()(s))
+        finally:
+            np.random.RandomState = RS
+        fired |= {(i, f) for i, f in enumerate(trail)}
+        record("chain.%d" % b, tensors(s), dict(B=8, H=96, W=96, seed=46, b=b, py_seed=300 + b, np_seed=300 + b,
+                                                noise_seed=2000 + b, fired=trail), b == 0)
+    assert len(fired) == 8, "the chain seeds must exercise both branches of all four transforms: %s" % sorted(fired)
+    with open(os.path.join(HERE, "input_pipeline.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "input_pipeline_small.npz"), **small)
+    print("input pipeline: %d cases, %d arrays kept in full" % (len(meta), len(small)))
+
+
 if __name__ == "__main__":
     import tempfile
     install_reference()
-    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn", "tn"]
+    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn", "tn", "input"]
+    if "input" in which:
+        make_input_pipeline()
+        if which == ["input"]:
+            raise SystemExit(0)
     if "tn" in which:        # TransNorm variant (--use_TN, SURVEY.md 8f-3): B = 4 so each domain half has 2 images
         mt = make_manifest("mobilenet", "manifest_tn.json", sync_bn=False)
         make_forward(mt, 4, 64, "tn_64")

@@ -12,7 +12,8 @@
 //                          uint8, mode 'reflect'.
 //   uda_elastic_warp   custom_transforms.py:95-147 (elastic_transform): bilinear map_coordinates of the image (constant 0
 //                      outside) and of the label (nearest edge outside) along a displacement field, rounded to uint8.
-//   uda_field_smooth   the separable Gaussian (mode 'constant') that turns the uniform noise into that displacement field.
+//   uda_field_smooth   the separable float64 Gaussian (mode 'constant') that turns the uniform noise into that displacement
+//                      field, in scipy's summation order (bit-identical field).
 //
 // All kernels are HBM-bound byte work: one coalesced pass per plane, halo rows/columns through LDS or the L2.
 #include "common.h"
@@ -135,82 +136,88 @@ extern "C" int uda_normalize_tf(const uint8_t* image_hwc, const uint8_t* label, 
 }
 
 // ------------------------------------------------------------------------------------------ elastic deformation
-// One separable pass of scipy.ndimage.gaussian_filter(field, sigma, mode='constant', cval=0) along AXIS on float planes
-// (weights from the host as numpy computes them).  The radius is large (0.32 * side: 164 taps each way at 512), so the
-// operand is staged in LDS once per workgroup and every staged value feeds FS_RUN outputs from registers:
-//   tile = FS_RUN * FS_GROUPS outputs along the smoothed axis x 64 lines across it; a wave's 64 lanes are 64 different
-//   LINES (LDS image [position][line], line stride 65 -> conflict-free for the transposed fill and for the reads),
-//   a thread owns FS_RUN consecutive outputs of its line: out[j] += w[|i - j|] * s[i] while i walks the run + halo once.
-// fp32 accumulation (329 terms of O(1e-2): ~1e-6 relative, i.e. ~1e-5 px of a 4 px displacement).
+// One separable pass of scipy.ndimage.gaussian_filter(field, sigma, mode='constant', cval=0) along AXIS on float64 planes,
+// EXACTLY as scipy computes it (the reference feeds float64 noise, custom_transforms.py:116-117, and the warp below rounds the
+// interpolated greys to uint8: a field that differs in its last bits flips ~1e-3 of the output bytes, so fp32 or another
+// summation order is not byte-identical to the reference).  correlate1d's symmetric branch (ni_filters.c):
+//     tmp = x[c] * w[0];  for d = R .. 1:  tmp += (x[c - d] + x[c + d]) * w[d]        (no fused multiply-add)
+// The radius is large (0.32 * side: 164 taps each way at 512), so the operand is staged in LDS once per workgroup:
+//   tile = FS_RUN * FS_GROUPS outputs along the smoothed axis x FS_LINES lines across it, LDS image [position][line] with a
+//   line stride of FS_LD doubles; a thread owns FS_RUN consecutive outputs of its line and walks d from R down to 1 with two
+//   sliding register windows (the left taps shift right, the right taps shift left: two new LDS operands and one weight per d
+//   feed FS_RUN pair-sums), so every accumulator sees its terms in scipy's order.
 #define FS_RUN 8
 #define FS_GROUPS 16
 #define FS_TILE (FS_RUN * FS_GROUPS)       // 128 outputs along the axis per workgroup
-#define FS_LINES 64
-#define FS_LD 65
+#define FS_LINES 32
+#define FS_LD 33
 
 template <int AXIS>
-__global__ __launch_bounds__(FS_GROUPS * FS_LINES) void field_smooth_kernel(const float* __restrict__ in, int H, int W,
-                                                                            const double* __restrict__ wts, int R, float scale,
-                                                                            float* __restrict__ out) {
-    extern __shared__ float fs_lds[];            // [FS_TILE + 2R][FS_LD] values, then [R + 1] weights
+__global__ __launch_bounds__(FS_GROUPS * FS_LINES) void field_smooth_kernel(const double* __restrict__ in, int H, int W,
+                                                                            const double* __restrict__ wts, int R, double scale,
+                                                                            int apply_scale, double* __restrict__ out) {
+    extern __shared__ double fs_lds[];            // [FS_TILE + 2R][FS_LD] values, then [R + 1] weights
     const int n = AXIS == 0 ? H : W, m = AXIS == 0 ? W : H;             // smoothed extent, number of lines
     const int span = FS_TILE + 2 * R;
-    float* wl = fs_lds + (size_t)span * FS_LD;
+    double* wl = fs_lds + (size_t)span * FS_LD;
     const int b = blockIdx.z, a0 = blockIdx.x * FS_TILE, l0 = blockIdx.y * FS_LINES;
-    const float* I = in + (int64_t)b * H * W;
+    const double* I = in + (int64_t)b * H * W;
     const int tid = threadIdx.x;
-    for (int k = tid; k <= R; k += blockDim.x) wl[k] = (float)wts[k];
-    // fill: element (position a0 - R + i, line l0 + l); zeros outside the plane ('constant' mode)
+    for (int k = tid; k <= R; k += blockDim.x) wl[k] = wts[k];
+    // fill: element (position a0 - R + i, line l0 + l); zeros outside the plane ('constant' mode, cval 0)
     if (AXIS == 0) {        // lines are columns: consecutive threads take consecutive columns of one row (coalesced)
         for (int e = tid; e < span * FS_LINES; e += blockDim.x) {
             const int i = e / FS_LINES, l = e % FS_LINES;
             const int pos = a0 - R + i, line = l0 + l;
-            fs_lds[i * FS_LD + l] = (pos >= 0 && pos < n && line < m) ? I[(int64_t)pos * W + line] : 0.f;
+            fs_lds[i * FS_LD + l] = (pos >= 0 && pos < n && line < m) ? I[(int64_t)pos * W + line] : 0.0;
         }
     } else {                // lines are rows: consecutive threads walk along a row (coalesced), transposed into [position][line]
         for (int e = tid; e < span * FS_LINES; e += blockDim.x) {
             const int l = e / span, i = e % span;
             const int pos = a0 - R + i, line = l0 + l;
-            fs_lds[i * FS_LD + l] = (pos >= 0 && pos < n && line < m) ? I[(int64_t)line * W + pos] : 0.f;
+            fs_lds[i * FS_LD + l] = (pos >= 0 && pos < n && line < m) ? I[(int64_t)line * W + pos] : 0.0;
         }
     }
     __syncthreads();
     const int l = tid % FS_LINES, grp = tid / FS_LINES;
-    float acc[FS_RUN];
+    const double* col = fs_lds + (size_t)(grp * FS_RUN + R) * FS_LD + l;        // col[i * FS_LD]: operand i positions from the run's first output
+    double acc[FS_RUN], lo[FS_RUN], hi[FS_RUN];
+    const double w0 = wl[0];
 #pragma unroll
-    for (int j = 0; j < FS_RUN; ++j) acc[j] = 0.f;
-    const int base = grp * FS_RUN;                   // first output of the run, tile-relative; its LDS position is base + R
-    // wr[j] = w(i - j), w(x) = weight at distance |x| (0 beyond R): stepping i shifts the window by one, so every step costs
-    // one new weight (a broadcast LDS read) and one operand read for FS_RUN multiply-adds
-    float wr[FS_RUN];
+    for (int j = 0; j < FS_RUN; ++j) {
+        acc[j] = col[j * FS_LD] * w0;
+        lo[j] = col[(j - R) * FS_LD];           // x[c_j - R]
+        hi[j] = col[(j + R) * FS_LD];           // x[c_j + R]
+    }
+    for (int d = R; d >= 1; --d) {
+        const double wd = wl[d];
 #pragma unroll
-    for (int j = 1; j < FS_RUN; ++j) wr[j] = 0.f;
-    wr[0] = wl[R];
-#pragma unroll 8
-    for (int i = -R; i < FS_RUN + R; ++i) {          // i: operand position relative to the run's first output
-        const float v = fs_lds[(base + R + i) * FS_LD + l];
+        for (int j = 0; j < FS_RUN; ++j) acc[j] += (lo[j] + hi[j]) * wd;
+        // d -> d - 1: x[c_j - (d-1)] = x[c_{j+1} - d], x[c_j + (d-1)] = x[c_{j-1} + d]
 #pragma unroll
-        for (int j = 0; j < FS_RUN; ++j) acc[j] += wr[j] * v;
+        for (int j = 0; j < FS_RUN - 1; ++j) lo[j] = lo[j + 1];
+        lo[FS_RUN - 1] = col[(FS_RUN - d) * FS_LD];
 #pragma unroll
-        for (int j = FS_RUN - 1; j > 0; --j) wr[j] = wr[j - 1];
-        const int d = i + 1 < 0 ? -(i + 1) : i + 1;
-        wr[0] = d <= R ? wl[d] : 0.f;
+        for (int j = FS_RUN - 1; j > 0; --j) hi[j] = hi[j - 1];
+        hi[0] = col[(d - 1) * FS_LD];
     }
     const int line = l0 + l;
     if (line < m) {
 #pragma unroll
         for (int j = 0; j < FS_RUN; ++j) {
-            const int pos = a0 + base + j;
-            if (pos < n) out[(int64_t)b * H * W + (AXIS == 0 ? (int64_t)pos * W + line : (int64_t)line * W + pos)] = acc[j] * scale;
+            const int pos = a0 + grp * FS_RUN + j;
+            if (pos < n)
+                out[(int64_t)b * H * W + (AXIS == 0 ? (int64_t)pos * W + line : (int64_t)line * W + pos)] =
+                    apply_scale ? acc[j] * scale : acc[j];
         }
     }
 }
 
-extern "C" int uda_field_smooth(const float* noise, int B, int H, int W, const double* weights_dev, int radius, float alpha,
-                                float* tmp, float* out, void* stream) {
+extern "C" int uda_field_smooth(const double* noise, int B, int H, int W, const double* weights_dev, int radius, double alpha,
+                                double* tmp, double* out, void* stream) {
     UDA_REQUIRE(noise && weights_dev && tmp && out && B > 0 && H > 0 && W > 0 && radius >= 1, "uda_field_smooth: bad args");
-    const size_t lds = ((size_t)(FS_TILE + 2 * radius) * FS_LD + radius + 1) * sizeof(float);
-    UDA_REQUIRE(lds <= 160 * 1024, "uda_field_smooth: radius %d needs %zu B of LDS (limit 160 KiB: sigma up to ~60)", radius, lds);
+    const size_t lds = ((size_t)(FS_TILE + 2 * radius) * FS_LD + radius + 1) * sizeof(double);
+    UDA_REQUIRE(lds <= 160 * 1024, "uda_field_smooth: radius %d needs %zu B of LDS (limit 160 KiB: sigma up to ~61, sides up to ~768)", radius, lds);
     hipStream_t st = (hipStream_t)stream;
     static bool configured = false;
     if (!configured) {
@@ -220,10 +227,10 @@ extern "C" int uda_field_smooth(const float* noise, int B, int H, int W, const d
         configured = true;
     }
     hipLaunchKernelGGL(field_smooth_kernel<0>, dim3(uda_cdiv(H, FS_TILE), uda_cdiv(W, FS_LINES), B), dim3(FS_GROUPS * FS_LINES), lds, st,
-                       noise, H, W, weights_dev, radius, 1.f, tmp);
+                       noise, H, W, weights_dev, radius, 1.0, 0, tmp);
     UDA_LAUNCH_CHECK("field_smooth axis 0");
     hipLaunchKernelGGL(field_smooth_kernel<1>, dim3(uda_cdiv(W, FS_TILE), uda_cdiv(H, FS_LINES), B), dim3(FS_GROUPS * FS_LINES), lds, st,
-                       tmp, H, W, weights_dev, radius, alpha, out);
+                       tmp, H, W, weights_dev, radius, alpha, 1, out);
     UDA_LAUNCH_CHECK("field_smooth axis 1");
     return 0;
 }
@@ -232,7 +239,7 @@ extern "C" int uda_field_smooth(const float* noise, int B, int H, int W, const d
 // label its nearest edge value ('nearest'); results are rounded to uint8 as scipy does for integer outputs.  `apply[b]` = 0 copies the
 // sample through (the transform fires with p = 0.5 per sample).
 __global__ __launch_bounds__(256) void elastic_warp_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ lab,
-                                                           const float* __restrict__ dx, const float* __restrict__ dy,
+                                                           const double* __restrict__ dx, const double* __restrict__ dy,
                                                            const uint8_t* __restrict__ apply, int H, int W,
                                                            uint8_t* __restrict__ img_out, uint8_t* __restrict__ lab_out) {
     const int b = blockIdx.z, h = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256) void elastic_warp_kernel(const uint8_t* __rest
         lab_out[o] = L[(int64_t)h * W + w];
         return;
     }
-    const double y = (double)h + (double)dx[o], x = (double)w + (double)dy[o];      // the reference adds dx to the ROW index
+    const double y = (double)h + dx[o], x = (double)w + dy[o];      // the reference adds dx to the ROW index
     const double fy = floor(y), fx = floor(x);
     const int y0 = (int)fy, x0 = (int)fx;
     const double ty = y - fy, tx = x - fx;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void elastic_warp_kernel(const uint8_t* __rest
     lab_out[o] = (uint8_t)(lv + 0.5);
 }
 
-extern "C" int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const float* dx, const float* dy,
+extern "C" int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const double* dx, const double* dy,
                                 const uint8_t* apply, int B, int H, int W, uint8_t* image_out, uint8_t* label_out, void* stream) {
     UDA_REQUIRE(image_hwc && label && dx && dy && image_out && label_out && B > 0 && H > 1 && W > 1, "uda_elastic_warp: bad args");
     UDA_REQUIRE(image_hwc != image_out && label != label_out, "uda_elastic_warp: cannot run in place");

@@ -129,7 +129,9 @@ class add_salt_pepper_noise(object):
         sp = None
         if seed > 0.5:
             n = int(np.ceil(amount * image.size * (salt_vs_pepper if seed > 0.75 else 1.0 - salt_vs_pepper)))
-            ys, xs = np.random.randint(0, image.shape[0] - 1, n), np.random.randint(0, image.shape[1] - 1, n)
+            # one draw per array axis, as the reference (custom_transforms.py:37,41): the third (channel) draw is never
+            # used but consumes np.random, which the eraser reads next
+            ys, xs, _ = [np.random.randint(0, i - 1, n) for i in image.shape]
             sp = (1 if seed > 0.75 else 0, ys, xs)
             if DEVICE_TAIL < 2:
                 image[ys, xs, :] = sp[0]
@@ -202,8 +204,8 @@ class Normalize_tf(object):
         if DEVICE_TAIL:
             out = {'image_u8': np.ascontiguousarray(np.array(sample['image']).astype(np.uint8)),
                    'label_u8': np.ascontiguousarray(np.array(sample['label']).astype(np.uint8)), 'img_name': sample['img_name']}
-            aug = sample.get('_aug')
-            if DEVICE_TAIL >= 2 and aug is not None:            # the recorded outcomes as fixed-size arrays (collate stacks them)
+            aug = sample.get('_aug') or {}                      # no record = no transform fired
+            if DEVICE_TAIL >= 2:                                # the recorded outcomes as fixed-size arrays (collate stacks them)
                 maxn = int(np.ceil(0.004 * out['image_u8'].size * 0.8))
                 pos = np.zeros((maxn, 2), np.int32)
                 val, ys, xs = aug.get('sp') or (0, (), ())

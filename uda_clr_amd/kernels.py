@@ -104,7 +104,7 @@ SYMBOLS = {
     "uda_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _U, _P]),
     "uda_normalize_tf_workspace_bytes": (_U, [_I, _I, _I]),
     "uda_normalize_tf": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _P, _P, _U, _P]),
-    "uda_field_smooth": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _P, _P]),
+    "uda_field_smooth": (_I, [_P, _I, _I, _I, _P, _I, _D, _P, _P, _P]),
     "uda_elastic_warp": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "uda_photometric_u8": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
 }
@@ -684,9 +684,10 @@ class HipKernels:
         return image, mp, bd
 
     def field_smooth(self, noise, sigma, alpha):
-        """alpha * gaussian_filter(noise, sigma, mode='constant') per [H,W] plane of a float32 [..., H, W] tensor."""
+        """alpha * scipy.ndimage.gaussian_filter(noise, sigma, mode='constant') per [H,W] plane of a float64 [..., H, W] tensor,
+        bit-identical to scipy (same taps, same summation order, no fused multiply-add)."""
         self._dev(noise)
-        assert noise.dtype == torch.float32 and noise.is_contiguous()
+        assert noise.dtype == torch.float64 and noise.is_contiguous()
         H, W = noise.shape[-2:]
         radius = int(4.0 * sigma + 0.5)
         wts = torch.from_numpy(self.gaussian_weights(sigma, radius)).to(noise.device)
@@ -701,7 +702,7 @@ class HipKernels:
             assert t.is_contiguous()
         B, H, W, ch = image_u8.shape
         assert ch == 3 and tuple(label_u8.shape) == (B, H, W) == tuple(dx.shape) == tuple(dy.shape)
-        assert image_u8.dtype == label_u8.dtype == torch.uint8 and dx.dtype == dy.dtype == torch.float32
+        assert image_u8.dtype == label_u8.dtype == torch.uint8 and dx.dtype == dy.dtype == torch.float64
         if apply is not None:
             assert apply.dtype == torch.uint8 and apply.numel() == B and apply.is_cuda
         io, lo = torch.empty_like(image_u8), torch.empty_like(label_u8)

@@ -181,17 +181,19 @@ def normalize_tf(image_u8, label_u8):
 def elastic_deform(image_u8, label_u8, apply=None, noise=None, generator=None):
     """Device-side ``elastic_transform`` (custom_transforms.py:95-147) of a uint8 batch: per sample with ``apply[b]`` set
     (default: drawn with p = 0.5) a displacement field alpha * gaussian_filter(U(-1,1), sigma), alpha = 2 * W, sigma = 0.08 * W,
-    bilinear resampling of the image (0 outside) and of the label (nearest edge).  ``noise`` ([2,B,H,W] float32 in [-1,1)) injects
-    the uniform fields (parity tests hand over numpy's draw); otherwise they come from torch's device generator - the random
-    STREAM then differs from numpy's, the distribution does not."""
+    bilinear resampling of the image (0 outside) and of the label (nearest edge).  Everything from the uniform noise on is the
+    reference's float64 arithmetic in the reference's order: with ``noise`` ([2,B,H,W] float64 in [-1,1), the two fields numpy's
+    ``RandomState.rand`` gave the reference) the output bytes equal the reference's (tests/test_input_golden_gpu.py).  Without it
+    the noise comes from torch's device generator - the reference seeds its RandomState from OS entropy, so there is no
+    stream to reproduce; the distribution is the same."""
     K = kernels()
     B, H, W, _ = image_u8.shape
     dev = image_u8.device
     if apply is None:
         apply = (torch.rand(B, generator=generator) > 0.5).to(torch.uint8).to(dev)
     if noise is None:
-        noise = torch.rand(2, B, H, W, device=dev, dtype=torch.float32) * 2.0 - 1.0
-    field = K.field_smooth(noise.contiguous(), 0.08 * W, 2.0 * W)
+        noise = torch.rand(2, B, H, W, device=dev, dtype=torch.float64) * 2.0 - 1.0
+    field = K.field_smooth(noise.to(torch.float64).contiguous(), 0.08 * W, 2.0 * W)
     return K.elastic_warp(image_u8.contiguous(), label_u8.contiguous(), field[0], field[1], apply)
 
 

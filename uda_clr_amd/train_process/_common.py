@@ -169,7 +169,10 @@ class TrainerBase(object):
             return sample
         iu, lu = self._to(sample['image_u8']), self._to(sample['label_u8'])
         if 'aug_lut' in sample:          # UDA_CLR_DEVICE_INPUT=2: the recorded elastic / photometric outcomes, in the chain's order
-            iu, lu = self.ops.elastic_deform(iu, lu, apply=self._to(sample['aug_elastic']).view(-1))
+            # 'aug_noise' ([B,2,H,W] float64): the uniform fields of the elastic transform when a caller supplies them (the parity
+            # tests hand over numpy's draw); normally absent - the noise then comes from the device generator
+            noise = self._to(sample['aug_noise']).transpose(0, 1).contiguous() if 'aug_noise' in sample else None
+            iu, lu = self.ops.elastic_deform(iu, lu, apply=self._to(sample['aug_elastic']).view(-1), noise=noise)
             iu = self.ops.photometric_u8(iu.contiguous(), self._to(sample['aug_sp_pos']), self._to(sample['aug_sp_n']),
                                          self._to(sample['aug_sp_val']), self._to(sample['aug_lut']), self._to(sample['aug_erase']))
         image, mp, bd = self.ops.normalize_tf(iu, lu)

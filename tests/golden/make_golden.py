@@ -304,21 +304,22 @@ def read_log(path):
     return rows
 
 
-def make_trainer_baseline(tmp):
-    """The reference's own Trainer_baseline loop on in-memory synthetic loaders (config 1 shape:
-    8 x 256^2 would take minutes; the fixture uses 4 x 64^2 for 2 epochs x 3 iterations)."""
+def make_trainer_baseline(tmp, S=64, B=4, nS=3, nV=2, epochs=2, seedS=500, seedV=700, fname="trainer_baseline.json"):
+    """The reference's own Trainer_baseline loop on in-memory synthetic loaders: 4 x 64^2 for 2 epochs x 3 iterations
+    (trainer_baseline.json), and the BASELINE.json configs[0] shape, 8 x 256^2, for one epoch of 4 iterations
+    (trainer_baseline_256.json: BN statistics over >= 2048 samples in every layer, so two fp32 evaluation orders stay on the same
+    trajectory)."""
     from train_process import Trainer_baseline
     from oracle import deeplab_ref, step_ref, metrics_ref
     m = ref_model()
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
-    S, B = 64, 4
-    loaderS, loaderV = synth_loader(3, B, S, 500), synth_loader(2, B, S, 700)
+    loaderS, loaderV = synth_loader(nS, B, S, seedS), synth_loader(nV, B, S, seedV)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
-    out = os.path.join(tmp, "baseline")
+    out = os.path.join(tmp, "baseline_%d" % S)
     torch.manual_seed(99)
     tr = Trainer_baseline.Trainer(cuda=False, model_gen=m, optimizer_gen=opt, lr_gen=1e-3,
                                   lr_decrease_rate=0.1, val_loader=loaderV, domain_loaderS=loaderS,
-                                  domain_loaderT=loaderS, out=out, max_epoch=2, stop_epoch=2,
+                                  domain_loaderT=loaderS, out=out, max_epoch=epochs, stop_epoch=epochs,
                                   interval_validate=1, batch_size=B, warmup_epoch=-1)
     tr.epoch = 0; tr.iteration = 0
     tr.train()
@@ -330,7 +331,7 @@ def make_trainer_baseline(tmp):
     oo = torch.optim.Adam(om.parameters(), lr=1e-3, betas=(0.9, 0.99))
     torch.manual_seed(99)
     mine, mval = [], []
-    for ep in range(2):
+    for ep in range(epochs):
         om.train()
         for s in loaderS:
             mine.append(step_ref.baseline_step(om, oo, s["image"], s["map"], s["boundary"]))
@@ -352,9 +353,9 @@ def make_trainer_baseline(tmp):
         tup = txt[txt.index("(") + 1: txt.index(")")].split(",")
         ref_val.append([float(v.replace("np.float64(", "").replace(")", "")) for v in tup])
     print("  val (reference):", ref_val, "\n  val (oracle)   :", mval)
-    with open(os.path.join(HERE, "trainer_baseline.json"), "w") as f:
-        json.dump({"S": S, "B": B, "loaderS_seed": 500, "loaderV_seed": 700, "n_batches_S": 3,
-                   "n_batches_V": 2, "epochs": 2, "torch_seed": 99, "train_loss": train_loss,
+    with open(os.path.join(HERE, fname), "w") as f:
+        json.dump({"S": S, "B": B, "loaderS_seed": seedS, "loaderV_seed": seedV, "n_batches_S": nS,
+                   "n_batches_V": nV, "epochs": epochs, "torch_seed": 99, "train_loss": train_loss,
                    "val": ref_val}, f)
 
 
@@ -522,7 +523,7 @@ def make_input_pipeline():
 if __name__ == "__main__":
     import tempfile
     install_reference()
-    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tp", "rn", "tn", "input"]
+    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tb256", "tp", "rn", "tn", "input"]
     if "input" in which:
         make_input_pipeline()
         if which == ["input"]:
@@ -552,6 +553,8 @@ if __name__ == "__main__":
     with tempfile.TemporaryDirectory() as tmp:
         if "tb" in which:
             make_trainer_baseline(tmp)
+        if "tb256" in which:
+            make_trainer_baseline(tmp, S=256, B=8, nS=4, nV=2, epochs=1, seedS=520, seedV=720, fname="trainer_baseline_256.json")
         if "tp" in which:
             make_trainer_proto(tmp)
     print("golden fixtures written to", HERE)

@@ -59,14 +59,14 @@ def _src_index(o, scale, n_in):
     return i0, i1, 1.0 - l1, l1
 
 
-def _bilinear_matrix(n_in, n_out, device):
+def _bilinear_matrix(n_in, n_out, device, dtype=torch.float32):
     """[n_out, n_in] interpolation matrix of align_corners=True bilinear resize."""
     scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
     o = torch.arange(n_out, device=device)
     i0, i1, l0, l1 = _src_index(o, torch.tensor(scale, dtype=torch.float32, device=device), n_in)
-    m = torch.zeros(n_out, n_in, device=device)
-    m[o, i0] += l0
-    m[o, i1] += l1
+    m = torch.zeros(n_out, n_in, device=device, dtype=dtype)      # lerp weights in fp32 like the kernels, whatever the value type
+    m[o, i0] += l0.to(dtype)
+    m[o, i1] += l1.to(dtype)
     return m
 
 
@@ -385,14 +385,14 @@ class SpecKernels:
     # ------------------------------------------------------------------ resampling / pooling
     def upsample_fwd(self, x, N, h, w, out, H, W):
         """Bilinear align_corners=True, NHWC [N*h*w, C] -> NHWC [N*H*W, C]."""
-        mh, mw = _bilinear_matrix(h, H, x.device), _bilinear_matrix(w, W, x.device)
+        mh, mw = _bilinear_matrix(h, H, x.device, x.dtype), _bilinear_matrix(w, W, x.device, x.dtype)
         t = x.reshape(N, h, w, -1)
         t = torch.einsum("Hh,nhwc->nHwc", mh, t)
         t = torch.einsum("Ww,nHwc->nHWc", mw, t)
         out.copy_(t.reshape(N * H * W, -1))
 
     def upsample_bwd(self, dout, N, H, W, dx, h, w):
-        mh, mw = _bilinear_matrix(h, H, dout.device), _bilinear_matrix(w, W, dout.device)
+        mh, mw = _bilinear_matrix(h, H, dout.device, dout.dtype), _bilinear_matrix(w, W, dout.device, dout.dtype)
         t = dout.reshape(N, H, W, -1)
         t = torch.einsum("Hh,nHWc->nhWc", mh, t)
         t = torch.einsum("Ww,nhWc->nhwc", mw, t)
@@ -401,7 +401,7 @@ class SpecKernels:
     @staticmethod
     def _upconv(g, N, h, w, H, W, C, dil):
         """sum over the 9 taps of shift_t(upsample(g_t)): upsample each tap plane, read it at p + d_t, zero outside."""
-        mh, mw = _bilinear_matrix(h, H, g.device), _bilinear_matrix(w, W, g.device)
+        mh, mw = _bilinear_matrix(h, H, g.device, g.dtype), _bilinear_matrix(w, W, g.device, g.dtype)
         t = g.reshape(N, h, w, 9, C)
         up = torch.einsum("Hh,Ww,nhwtc->ntHWc", mh.to(g.dtype), mw.to(g.dtype), t)
         out = torch.zeros(N, H, W, C, dtype=g.dtype, device=g.device)
@@ -430,13 +430,13 @@ class SpecKernels:
     def head_upsample_fwd(self, x, N, h, w, out):
         """NHWC [N*h*w, C<=2] -> contiguous NCHW [N, C, H, W] (bilinear, align_corners)."""
         H, W = out.shape[2], out.shape[3]
-        mh, mw = _bilinear_matrix(h, H, x.device), _bilinear_matrix(w, W, x.device)
+        mh, mw = _bilinear_matrix(h, H, x.device, x.dtype), _bilinear_matrix(w, W, x.device, x.dtype)
         t = x.reshape(N, h, w, -1)
         out.copy_(torch.einsum("Hh,Ww,nhwc->ncHW", mh, mw, t))
 
     def head_upsample_bwd(self, dout, dx, N, h, w, accumulate=False):
         H, W = dout.shape[2], dout.shape[3]
-        mh, mw = _bilinear_matrix(h, H, dout.device), _bilinear_matrix(w, W, dout.device)
+        mh, mw = _bilinear_matrix(h, H, dout.device, dout.dtype), _bilinear_matrix(w, W, dout.device, dout.dtype)
         t = torch.einsum("Hh,Ww,ncHW->nhwc", mh, mw, dout).reshape(N * h * w, -1)
         if accumulate:
             dx.add_(t)

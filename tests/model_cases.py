@@ -38,15 +38,13 @@ def l2rel(a, b, trim=0.01):
 
 def grad_ok(err_hip, err_fp32_oracle, factor=10.0):
     """Per-tensor gradient criterion.  The fp64 oracle is the ground truth; the fp32 oracle (= the
-    reference's own arithmetic) is itself 1e-3 .. 1e0 away from it on this network (BN-bias gradients are
-    sums with near-total cancellation), so the HIP path must stay within a multiple of THAT distance.
-    Two fp32 evaluation orders of an ill-conditioned sum differ by a heavy-tailed random factor, so the
-    per-tensor bound is 10x (30x for tensors that are noise-dominated in the reference's own arithmetic:
-    fp32-oracle distance above 5e-3, e.g. the bias of the BN that feeds the ASPP's BatchNorms, whose true
-    gradient is ~0) and ``grads_ok`` adds a bound of 4x on the geometric mean over all tensors (a wrong
-    kernel moves a tensor by O(1), i.e. 100-1000x its fp32 distance)."""
-    if err_fp32_oracle > 5e-3:
-        factor = 3.0 * factor
+    reference's own arithmetic) is itself 1e-4 .. 1e-2 away from it on this network (BN-bias gradients are
+    sums with near-total cancellation, and one ReLU gate whose pre-activation sits within rounding of 0 moves
+    a whole layer's gradient by ~1e-3), so the HIP path must stay within a multiple of THAT distance:
+    10x per tensor (two fp32 evaluation orders of an ill-conditioned sum differ by a heavy-tailed random
+    factor) + 2e-3, and ``grads_ok`` bounds the geometric mean over all tensors by 1.5 (measured on MI355X:
+    0.70 at 512^2, 0.77 at 64^2 - the HIP gradients are closer to fp64 than the reference's own fp32;
+    a wrong kernel moves a tensor by O(1), i.e. 100-1000x its fp32 distance)."""
     return err_hip < factor * err_fp32_oracle + 2e-3
 
 

@@ -15,14 +15,18 @@ def test_eval_forward_matches_oracle(size):
     assert max(errs.values()) < 1e-3, errs          # north_star tolerance: 1e-3 relative fp32
 
 
-def test_train_forward_backward_matches_oracle():
-    fwd, grads, stats, _ = model_cases.train_parity(DEV)
+@pytest.mark.parametrize("size", [64, 512])
+def test_train_forward_backward_matches_oracle(size):
+    """B = 2 at 64^2 (deepest BNs over 32 samples) and at the training resolution 512^2."""
+    fwd, grads, stats, _ = model_cases.train_parity(DEV, S=size)
     assert max(fwd.values()) < 1e-3, fwd
     assert stats < 1e-3
-    # gradients (L2): within a small multiple of the fp32 oracle's own distance to the fp64 oracle
+    # gradients (L2): every tensor within 10x the fp32 oracle's own distance to the fp64 oracle, and on (geometric) average
+    # no further from fp64 than 1.5x the reference's own fp32 arithmetic (measured: 0.77 / 0.70)
     bad, gmean = model_cases.grads_ok(grads)
+    print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
     assert not bad, list(bad.items())[:10]
-    assert gmean < 4.0, gmean
+    assert gmean < 1.5, gmean
 
 
 @pytest.mark.parametrize("tag", ["64", "512"])
@@ -48,6 +52,7 @@ def test_resnet_train_forward_backward_matches_oracle():
         assert e < 3.0 * floor + 2e-4, (n, e, floor)
     assert stats < 5e-3
     bad, gmean = model_cases.grads_ok(grads)
+    print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
     assert not bad, list(bad.items())[:10]
     assert gmean < 4.0, gmean
 
@@ -78,6 +83,7 @@ def test_transnorm_train_forward_backward_matches_oracle(B):
         assert e < 3.0 * floor + 2e-4, (n, e, floor)
     assert stats < 2e-3
     bad, gmean = model_cases.grads_ok(grads)
+    print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
     assert not bad, list(bad.items())[:10]
     assert gmean < 4.0, gmean
 
@@ -190,6 +196,7 @@ def test_odd_training_batch_and_non_square_backward():
     fwd, grads, stats, fwd64 = model_cases.train_parity(DEV, B=3, S=(64, 96))
     assert max(fwd.values()) < 1e-3, fwd
     bad, gmean = model_cases.grads_ok(grads)
+    print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
     assert not bad, list(bad.items())[:10]
     assert gmean < 4.0, gmean
 
@@ -257,5 +264,6 @@ def test_output_stride_8_forward_backward():
     assert max(fwd.values()) < 1e-3, fwd
     assert stats < 1e-3
     bad, gmean = model_cases.grads_ok(grads)
+    print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
     assert not bad, list(bad.items())[:10]
     assert gmean < 4.0, gmean

@@ -26,8 +26,10 @@ def _rows(path):
         return [l.split(",") for l in f.read().strip().split("\n")[1:]]
 
 
-def test_trainer_baseline_reproduces_reference_rows(golden_dir, tmp_path):
-    z = json.load(open(os.path.join(golden_dir, "trainer_baseline.json")))
+@pytest.mark.parametrize("fixture", ["trainer_baseline.json", "trainer_baseline_256.json"])
+def test_trainer_baseline_reproduces_reference_rows(golden_dir, tmp_path, fixture):
+    """trainer_baseline_256.json is the BASELINE.json configs[0] case: Trainer_baseline on 8 synthetic 256x256 pairs, CPU."""
+    z = json.load(open(os.path.join(golden_dir, fixture)))
     m = _oracle_model()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
     loaderS = synth_loader(z["n_batches_S"], z["B"], z["S"], z["loaderS_seed"])

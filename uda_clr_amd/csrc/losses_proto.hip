@@ -179,6 +179,7 @@ struct PwArgs {
 };
 
 __device__ __forceinline__ float bil_sample(const float* plane, int H, int W, int oh, int ow, float sh, float sw) {
+#pragma clang fp contract(off)      // source coordinates rounded to fp32 before the subtraction, as PyTorch (see bilinear.h)
     const float rh = sh * (float)oh, rw = sw * (float)ow;
     int h0 = (int)rh, w0 = (int)rw;
     if (h0 > H - 1) h0 = H - 1;

@@ -78,7 +78,8 @@ def test_trainer_baseline_hip_matches_reference_rows(golden_dir, tmp_path):
 def test_trainer_baseline_hip_matches_reference_rows_256(golden_dir, tmp_path):
     """BASELINE.json configs[0] shape (8 x 256^2, one epoch of 4 Adam steps + validation), rows written by the reference's own
     Trainer_baseline: every BatchNorm sees >= 2048 samples, so two fp32 evaluation orders stay on one trajectory and the
-    whole epoch is held to 2 % (first step, a pure forward quantity: 1e-3), validation loss to 5 %, Dice to 0.05."""
+    whole epoch is held to 1 % (first step, a pure forward quantity: 1e-3; measured 0.3 % after 3 Adam steps), validation loss
+    to 2 %, Dice to 0.01."""
     z = json.load(open(os.path.join(golden_dir, "trainer_baseline_256.json")))
     m = MaskFeeder(model_cases.seeded_model().to(DEV))
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
@@ -96,14 +97,14 @@ def test_trainer_baseline_hip_matches_reference_rows_256(golden_dir, tmp_path):
     train = [float(r[2]) for r in rows if r[2] != ""]
     print("train rows hip", train, "reference", z["train_loss"])
     assert abs(train[0] - z["train_loss"][0]) < 1e-3 * z["train_loss"][0]
-    np.testing.assert_allclose(train, z["train_loss"], rtol=2e-2)
+    np.testing.assert_allclose(train, z["train_loss"], rtol=1e-2)
     val = [r for r in rows if r[2] == ""]
     assert len(val) == len(z["val"]) == 1
     txt = ",".join(val[0])
     got = [float(v) for v in txt[txt.index("(") + 1: txt.index(")")].split(",")]
     print("val hip", got, "reference", z["val"][0])
-    assert abs(got[0] - z["val"][0][0]) < 0.05 * abs(z["val"][0][0])
-    assert abs(got[1] - z["val"][0][1]) < 0.05 and abs(got[2] - z["val"][0][2]) < 0.05
+    assert abs(got[0] - z["val"][0][0]) < 0.02 * abs(z["val"][0][0])
+    assert abs(got[1] - z["val"][0][1]) < 0.01 and abs(got[2] - z["val"][0][2]) < 0.01
 
 
 def test_trainer_prototype_full_hip_matches_reference_rows(golden_dir, tmp_path):
@@ -128,5 +129,5 @@ def test_trainer_prototype_full_hip_matches_reference_rows(golden_dir, tmp_path)
     ref = np.array(z["rows"])
     print("rows hip", rows.tolist(), "reference", ref.tolist())
     np.testing.assert_allclose(rows[0], ref[0], rtol=1e-3)                # first iteration: forward-only quantities, incl. intra / inter
-    np.testing.assert_allclose(rows[:, :4], ref[:, :4], rtol=5e-2)        # after an Adam step (see the baseline test)
-    np.testing.assert_allclose(rows[:, 4:], ref[:, 4:], rtol=1e-1)
+    np.testing.assert_allclose(rows[:, :4], ref[:, :4], rtol=5e-3)        # after an Adam step (measured 7e-4 on seg, 1e-5 on the adversarial terms)
+    np.testing.assert_allclose(rows[:, 4:], ref[:, 4:], rtol=6e-2)        # prototype distances after the step (B = 2: measured 3.7e-2)

@@ -473,8 +473,9 @@ class SpecKernels:
         return torch.stack([bce + mse, bce, mse])
 
     def seg_loss_bwd(self, o, tmap, b, tbd, gscale):
-        o2, b2 = o.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
-        (F.binary_cross_entropy(torch.sigmoid(o2), tmap) + F.mse_loss(torch.sigmoid(b2), tbd)).backward()
+        with torch.enable_grad():          # also callable from inside an autograd backward (grad mode is off there)
+            o2, b2 = o.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+            (F.binary_cross_entropy(torch.sigmoid(o2), tmap) + F.mse_loss(torch.sigmoid(b2), tbd)).backward()
         return o2.grad * gscale, b2.grad * gscale
 
     def seg_counts(self, logits, target, thr):

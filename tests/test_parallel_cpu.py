@@ -2,7 +2,7 @@
   - FlatGradAllReduce averages gradients (missing grads count as zero) and leaves all ranks equal
   - all_reduce_sum_ of per-rank prototype sums == sums of the concatenated batch (so centroids are
     the global-batch centroids), AllReduceSum back-propagates the identity
-  - loader sharding gives disjoint, complete coverage
+  - loader sharding gives complete coverage with the SAME number of iterations on every rank (wrap-around padding)
   - the product Trainer_baseline steps two ranks in lock-step: identical parameters afterwards and
     equal to averaging the two ranks' single-process gradients by hand."""
 import os
@@ -50,8 +50,8 @@ def _worker_utils(rank, world, port, out):
     y = parallel.AllReduceSum.apply(x * 2.0)
     y.sum().backward()
     assert torch.allclose(x.grad, torch.full_like(x, 2.0))
-    seen = [i for i in shard_loader(list(range(7)), rank, world)]
-    assert seen == list(range(rank, 7, world)) and len(shard_loader(list(range(7)), rank, world)) == len(seen)
+    seen = [i for i in shard_loader(list(range(7)), rank, world)]      # 7 batches on 2 ranks: 4 each, the last one wraps around
+    assert seen == [(i * world + rank) % 7 for i in range(4)] and len(shard_loader(list(range(7)), rank, world)) == 4
     open(os.path.join(out, "ok%d" % rank), "w").write("1")
     dist.destroy_process_group()
 
@@ -120,3 +120,165 @@ def test_trainer_baseline_data_parallel_gloo_world2():
         for k in p0:
             want = init[k] - 0.1 * 0.5 * (grads[0][k] + grads[1][k])
             assert torch.allclose(p0[k], want, rtol=1e-5, atol=1e-6), k
+
+
+# ---------------------------------------------------------------- equal iteration counts on every rank
+def test_shard_loader_gives_every_rank_the_same_number_of_batches_and_no_single_image_batch():
+    """n = 385, world 8, batch 16 (the example of the round-1 review: rank 0 got 4 batches incl. a 1-image one, the others 3):
+    every rank now iterates the same number of batches, none of size 1, and the ranks together cover the dataset."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from uda_clr_amd.train_process._common import shard_count, shard_loader
+    for n, world, bs, shuffle in ((385, 8, 16, True), (385, 8, 16, False), (33, 2, 16, True), (7, 2, 4, False), (5, 4, 2, True),
+                                  (64, 8, 8, True)):
+        ds = TensorDataset(torch.arange(n))
+        base = DataLoader(ds, batch_size=bs, shuffle=shuffle, drop_last=False)
+        per_rank = []
+        for epoch in range(2):
+            seen, counts = [], []
+            loaders = per_rank or [shard_loader(base, r, world, seed=123) for r in range(world)]
+            per_rank = loaders
+            for ld in loaders:
+                batches = [b[0].tolist() for b in ld]
+                assert len(batches) == len(ld)
+                counts.append(len(batches))
+                assert all(len(b) >= 2 for b in batches) or shard_count(n, world, bs) == 1, (n, world, bs, [len(b) for b in batches])
+                seen.append([i for b in batches for i in b])
+            assert len(set(counts)) == 1, (n, world, bs, counts)
+            assert len({len(s) for s in seen}) == 1
+            union = set(i for s in seen for i in s)
+            dropped = n - len(union)
+            assert dropped <= world, (n, world, bs, dropped)            # only the trailing single-image batches are given up
+            if shuffle and n > 2 * world:
+                flat0 = seen[0]
+                if epoch == 0:
+                    first_epoch = flat0
+                else:
+                    assert flat0 != first_epoch, "the global order must change from epoch to epoch"
+    # plain sequences of batches: wrapped around to a common count
+    for n, world in ((7, 2), (3, 4), (8, 4)):
+        lens = [len(list(shard_loader(list(range(n)), r, world))) for r in range(world)]
+        assert len(set(lens)) == 1 and lens[0] == (n + world - 1) // world
+        assert set(i for r in range(world) for i in shard_loader(list(range(n)), r, world)) == set(range(n))
+
+
+# ---------------------------------------------------------------- Trainer_prototype_full under data parallelism
+def _proto_setup(seed_dis=1338):
+    from oracle import deeplab_ref
+    from oracle.gan_ref import BoundaryDiscriminator, UncertaintyDiscriminator
+    from uda_clr_amd.networks.deeplabv3 import DeepLab
+    torch.manual_seed(1337)
+    m = deeplab_ref.OracleDeepLab(DeepLab(num_classes=2, backbone="mobilenet", output_stride=16).state_dict())
+    torch.manual_seed(seed_dis)
+    d1, d2 = BoundaryDiscriminator(), UncertaintyDiscriminator()
+    return m, d1, d2
+
+
+_PF = dict(S=128, B=2, lr=0.05, lr_d=0.01, pro_weight=0.1, loaderS_seed=80, loaderT_seed=90, drop_seed=500)
+
+
+def _worker_proto(rank, world, port, out):
+    _init(rank, world, port)
+    from kernel_spec import SpecKernels
+    from make_golden_inputs import synth_loader
+    from uda_clr_amd import ops
+    from uda_clr_amd.train_process import Trainer_prototype_full
+    ops._K = SpecKernels()          # the product's front-ends (incl. the prototype all-reduce) on the torch statement of the kernels
+    c = _PF
+    m, d1, d2 = _proto_setup()
+    if rank == 1:                   # a replica that starts apart: the Trainer must bring it back to rank 0's state
+        with torch.no_grad():
+            for p in list(m.parameters())[:3] + list(d1.parameters())[:1]:
+                p.add_(0.5)
+            next(iter(m.buffers())).add_(1.0)
+    og = torch.optim.SGD(m.parameters(), lr=c["lr"])
+    od, od2 = torch.optim.SGD(d1.parameters(), lr=c["lr_d"]), torch.optim.SGD(d2.parameters(), lr=c["lr_d"])
+    loaderS = synth_loader(2, c["B"], c["S"], c["loaderS_seed"])     # rank r trains on batch r of each domain
+    loaderT = synth_loader(2, c["B"], c["S"], c["loaderT_seed"])
+    tr = Trainer_prototype_full.Trainer(cuda=False, model_gen=m, model_dis=d1, model_uncertainty_dis=d2, optimizer_gen=og,
+                                        optimizer_dis=od, optimizer_uncertainty_dis=od2, val_loader=loaderT, domain_loaderS=loaderS,
+                                        domain_loaderT=loaderT, out=os.path.join(out, "run"), max_epoch=1, use_global=True, use_pid=True,
+                                        retrify_pesudo=True, global_pro_weight=0.9, pro_weight=c["pro_weight"], stop_epoch=1,
+                                        interval_validate=100, batch_size=c["B"], warmup_epoch=-1)
+    assert tr.world == 2 and len(tr.domain_loaderS) == 1 and len(tr.domain_loaderT) == 1
+    tr.epoch = 0
+    tr.iteration = 0
+    m.train(); d1.train(); d2.train()
+    torch.manual_seed(c["drop_seed"] + rank)         # each rank its own dropout stream (reproduced by the hand-made reference)
+    vals = tr.train_step(next(iter(tr.domain_loaderS)), next(iter(tr.domain_loaderT)))
+    torch.save({"gen": {k: v.detach().clone() for k, v in m.named_parameters()},
+                "dis": {k: v.detach().clone() for k, v in d1.named_parameters()},
+                "dis2": {k: v.detach().clone() for k, v in d2.named_parameters()},
+                "src": [t.clone() for t in tr.src_centroids], "tgt": [t.clone() for t in tr.tgt_centroids], "vals": vals},
+               os.path.join(out, "pf%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_trainer_prototype_full_data_parallel_gloo_world2():
+    """BASELINE.json configs[3] in miniature: two ranks x (B source + B target) through the product Trainer_prototype_full on
+    the product's prototype front-ends (sum all-reduce of the [4][C+1] sums before the division, identity backward, alignment
+    loss weighted by world before the averaged backward).  Checked against a single-process hand-made statement:
+      * both ranks end with IDENTICAL parameters (generator and both discriminators), although rank 1 started perturbed;
+      * the centroids on both ranks are the centroids of the CONCATENATED batch;
+      * the update equals one SGD step on  mean_r(seg_r + adv_r) + pro_weight * intra(global centroids)."""
+    sys.path.insert(0, HERE)
+    import torch.nn.functional as F
+    from make_golden_inputs import synth_loader
+    from oracle import proto_ref, step_ref
+    c = _PF
+    with tempfile.TemporaryDirectory() as out:
+        _spawn(_worker_proto, out)
+        r0, r1 = torch.load(os.path.join(out, "pf0.pt")), torch.load(os.path.join(out, "pf1.pt"))
+    for grp in ("gen", "dis", "dis2"):
+        for k in r0[grp]:
+            assert torch.equal(r0[grp][k], r1[grp][k]), "ranks diverged on %s %s" % (grp, k)
+    for a, b in zip(r0["src"] + r0["tgt"], r1["src"] + r1["tgt"]):
+        assert torch.equal(a, b), "the ranks hold different centroids"
+    assert r0["vals"][4:] == r1["vals"][4:], "intra / inter are global quantities"
+    # ---- hand-made single-process statement
+    m, d1, d2 = _proto_setup()
+    m.train(); d1.train(); d2.train()
+    init = {g: {k: v.detach().clone() for k, v in mod.named_parameters()} for g, mod in (("gen", m), ("dis", d1), ("dis2", d2))}
+    loaderS, loaderT = synth_loader(2, c["B"], c["S"], c["loaderS_seed"]), synth_loader(2, c["B"], c["S"], c["loaderT_seed"])
+    per = []
+    for r in range(2):
+        torch.manual_seed(c["drop_seed"] + r)
+        sS, sT = loaderS[r], loaderT[r]
+        oT, bT, _, _, xt, oT_before, _ = m(sT["image"])
+        oS, bS, _, _, xs, _, _ = m(sS["image"])
+        rep = sT["image"].repeat(2, 1, 1, 1)
+        with torch.no_grad():
+            preds = torch.cat([m(rep)[0] for _ in range(4)], 0)
+        per.append(dict(oT=oT, bT=bT, xt=xt, oTb=oT_before, oS=oS, bS=bS, xs=xs, preds=preds, sS=sS))
+    # global source centroids: labels nearest-resized, features of both ranks concatenated
+    lab = torch.cat([F.interpolate(p["sS"]["map"].clone(), size=p["xs"].shape[2:], mode="nearest") for p in per])
+    src = proto_ref.gen_prototype(lab, torch.cat([p["xs"] for p in per]))
+    # global target centroids: the retrify weights are per pixel, so the concatenated batch gives the concatenated weights
+    T = 8
+    preds_cat = torch.cat([torch.cat([p["preds"][i * c["B"]:(i + 1) * c["B"]] for p in per]) for i in range(T)])
+    tgt = proto_ref.gen_prototype_retrify(torch.cat([p["oTb"] for p in per]), torch.cat([p["xt"] for p in per]), preds_cat, T,
+                                          2 * c["B"])[:4]
+    for got, want in zip(r0["src"] + r0["tgt"], src + tgt):
+        assert torch.allclose(got, want.detach(), rtol=1e-4, atol=1e-6), "centroids are not those of the global batch"
+    intra, inter = proto_ref.alignment_losses(src, tgt)
+    assert abs(r0["vals"][4] - intra.item()) < 1e-4 * abs(intra.item()) and abs(r0["vals"][5] - inter.item()) < 1e-4 * abs(inter.item())
+    total = c["pro_weight"] * intra
+    for p in per:
+        adv = 0.01 * (step_ref._adv(d2(step_ref._uncertainty(p["oT"])), 1) + step_ref._adv(d1(torch.sigmoid(p["bT"])), 1))
+        total = total + 0.5 * (step_ref.seg_loss(p["oS"], p["bS"], p["sS"]["map"], p["sS"]["boundary"]) + adv)
+    gp = [q for q in m.parameters()]
+    grads = torch.autograd.grad(total, gp, allow_unused=True)
+    worst = 0.0
+    for (k, v0), g in zip(init["gen"].items(), grads):
+        want = v0 if g is None else v0 - c["lr"] * g
+        assert torch.allclose(r0["gen"][k], want, rtol=2e-4, atol=2e-6), (k, (r0["gen"][k] - want).abs().max().item())
+        worst = max(worst, (r0["gen"][k] - want).abs().max().item())
+    # discriminators: mean over ranks of (D_same_r + D_diff_r) on detached generator outputs
+    dl = 0.0
+    for p in per:
+        oS, bS, oT, bT = (p[k].detach() for k in ("oS", "bS", "oT", "bT"))
+        dl = dl + 0.5 * (step_ref._adv(d2(step_ref._uncertainty(oS)), 1) + step_ref._adv(d1(torch.sigmoid(bS)), 1) +
+                         step_ref._adv(d2(step_ref._uncertainty(oT)), 0) + step_ref._adv(d1(torch.sigmoid(bT)), 0))
+    for grp, mod in (("dis", d1), ("dis2", d2)):
+        ps = list(mod.parameters())
+        for (k, v0), g in zip(init[grp].items(), torch.autograd.grad(dl, ps, retain_graph=True)):
+            assert torch.allclose(r0[grp][k], v0 - c["lr_d"] * g, rtol=2e-4, atol=1e-7), (grp, k)

@@ -97,6 +97,12 @@ class DeepLab(Holder):
         """Parity tests: keep-masks ({site: uint8 NCHW}) used by the next training forward."""
         self._next_masks = masks
 
+    def set_dropout_seed(self, seed):
+        """Philox key of the dropout masks (data-parallel trainers give every rank its own)."""
+        self._dropout_seed = int(seed)
+        if self._engine is not None:
+            self._engine.seed = self._dropout_seed
+
     def _remember(self, x, ectx):
         self._recent = [(x.data_ptr(), tuple(x.shape), ectx)] + self._recent[:1]
 
@@ -161,7 +167,7 @@ class DeepLab(Holder):
         if self._engine is None:
             from ..kernels import HipKernels
             self._engine = GeneratorEngine(HipKernels(), self.output_stride, backbone=self.backbone_name,
-                                           transnorm=self.transnorm)
+                                           transnorm=self.transnorm, seed=getattr(self, "_dropout_seed", 1337))
         return self._engine
 
     def forward(self, input):

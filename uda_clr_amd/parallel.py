@@ -65,8 +65,3 @@ def all_reduce_sum_(t):
     if world() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
-
-
-def shard_indices(n, rank, world_size):
-    """Dataset index striding by rank."""
-    return list(range(rank, n, world_size))

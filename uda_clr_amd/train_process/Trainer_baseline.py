@@ -15,7 +15,8 @@ import timeit
 import torch
 
 from ..parallel import FlatGradAllReduce
-from ._common import HipOps, TrainerBase, get_lr, nan_guard, prefer_fused, progress, shard_loader, trange
+from ._common import (HipOps, TrainerBase, decorrelate_dropout, get_lr, nan_guard, prefer_fused, progress, shard_loader,
+                      sync_replicas, trange)
 
 
 class Trainer(TrainerBase):
@@ -39,6 +40,8 @@ class Trainer(TrainerBase):
         self.domain_loaderT = shard_loader(domain_loaderT, self.rank, self.world)
         self.ops = HipOps()
         self._reducer = FlatGradAllReduce(list(model_gen.parameters())) if self.world > 1 else None
+        sync_replicas((model_gen,), self.rank, self.world)
+        decorrelate_dropout(model_gen, self.rank, self.world)
         self.epoch = 0
         self.iteration = 0
         self.max_epoch = max_epoch

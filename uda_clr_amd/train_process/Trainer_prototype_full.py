@@ -31,7 +31,8 @@ import torch
 import torch.nn.functional as F
 
 from ..parallel import FlatGradAllReduce
-from ._common import HipOps, TrainerBase, get_lr, nan_guard, prefer_fused, progress, shard_loader, trange
+from ._common import (HipOps, TrainerBase, decorrelate_dropout, get_lr, nan_guard, prefer_fused, progress, shard_loader,
+                      sync_replicas, trange)
 
 mseloss = torch.nn.MSELoss()
 
@@ -86,6 +87,8 @@ class Trainer(TrainerBase):
         self._reducers = None
         if self.world > 1:
             self._reducers = [FlatGradAllReduce(list(m.parameters())) for m in (model_gen, model_dis, model_uncertainty_dis)]
+            sync_replicas((model_gen, model_dis, model_uncertainty_dis), self.rank, self.world)
+            decorrelate_dropout(model_gen, self.rank, self.world)
         self.epoch = 0
         self.iteration = 0
         self.max_epoch = max_epoch

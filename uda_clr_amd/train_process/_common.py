@@ -101,35 +101,117 @@ def bootstrap_from_env():
         dist.init_process_group("gloo")
 
 
+def agree_int(value):
+    """The same integer on every rank (rank 0's), e.g. a shuffling seed; identity for a single process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, 0)
+    return int(t.item())
+
+
+def shard_count(n, world, batch_size=None):
+    """Samples (or batches) every rank takes from n: ceil(n / world) - the set is padded by wrapping around, as
+    torch's DistributedSampler does, so ALL ranks run the same number of iterations (a rank with one batch less would
+    skip an all-reduce and hang the others).  With a batch size, a per-rank count that would leave a trailing batch of ONE
+    sample is shortened by that sample: the image-pooling BatchNorm cannot train on a single image (quirk Q8,
+    aspp.py:55-58) and would raise on every rank."""
+    if n <= 0:
+        return 0
+    L = (n + world - 1) // world
+    if batch_size and L > 1 and L % batch_size == 1:
+        L -= 1
+    return L
+
+
+class RankSampler(torch.utils.data.Sampler):
+    """Index stream of ONE rank: each epoch the same global order on every rank (a permutation drawn from ``seed + epoch``
+    when shuffling, else 0..n-1), wrapped around to world * L entries, of which this rank takes every world-th starting at
+    its rank (dataset index striding).  ``len`` is identical on all ranks."""
+
+    def __init__(self, n, rank, world, shuffle, seed, batch_size=None):
+        self.n, self.rank, self.world, self.shuffle, self.seed = n, rank, world, shuffle, int(seed)
+        self.L = shard_count(n, world, batch_size)
+        self.epoch = 0
+
+    def __len__(self):
+        return self.L
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        self.epoch += 1
+        need = self.world * self.L
+        order = (order * (need // max(len(order), 1) + 1))[:need] if order else []
+        return iter(order[self.rank:need:self.world])
+
+
 class _Strided:
-    """rank-strided view of a loader (dataset index striding)."""
+    """Rank-strided view of a sequence of ready-made batches: rank r takes batches r, r + world, ... wrapped around so that
+    every rank iterates ceil(n / world) times."""
     def __init__(self, loader, rank, world):
         self.loader, self.rank, self.world = loader, rank, world
 
     def __len__(self):
-        n = len(self.loader)
-        return (n - self.rank + self.world - 1) // self.world if n > self.rank else 0
+        return shard_count(len(self.loader), self.world)
 
     def __iter__(self):
-        for i, b in enumerate(self.loader):
-            if i % self.world == self.rank:
-                yield b
+        items = self.loader if hasattr(self.loader, "__getitem__") else list(self.loader)
+        n = len(items)
+        for i in range(shard_count(n, self.world)):
+            yield items[(i * self.world + self.rank) % n]
 
 
-def shard_loader(loader, rank, world):
-    """Every rank sees a disjoint 1/world of the BATCHES of an epoch.  DataLoaders are rebuilt over
-    a rank-strided subset of their dataset (keeps batch size / workers / collate); plain sequences
-    are strided directly."""
+def shard_loader(loader, rank, world, seed=None):
+    """Every rank sees 1/world of an epoch and ALL ranks run the same number of iterations (see ``shard_count``).
+    DataLoaders are rebuilt around a ``RankSampler`` (keeps batch size / workers / collate / pinning; the shuffling seed is
+    rank 0's, so the ranks agree on each epoch's order); plain sequences of batches are strided directly."""
     if world == 1 or loader is None:
         return loader
-    from torch.utils.data import DataLoader, Subset
+    from torch.utils.data import DataLoader
     if isinstance(loader, DataLoader):
-        idx = list(range(rank, len(loader.dataset), world))
-        return DataLoader(Subset(loader.dataset, idx), batch_size=loader.batch_size,
-                          shuffle=isinstance(loader.sampler, torch.utils.data.RandomSampler),
-                          num_workers=loader.num_workers, pin_memory=loader.pin_memory,
-                          collate_fn=loader.collate_fn, drop_last=loader.drop_last)
+        shuffle = isinstance(loader.sampler, torch.utils.data.RandomSampler)
+        if seed is None:
+            seed = agree_int(torch.initial_seed() % (2 ** 31))
+        sampler = RankSampler(len(loader.dataset), rank, world, shuffle, seed, loader.batch_size)
+        return DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
+                          pin_memory=loader.pin_memory, collate_fn=loader.collate_fn, drop_last=loader.drop_last)
     return _Strided(loader, rank, world)
+
+
+def sync_replicas(modules, rank, world):
+    """Data-parallel start state: parameters AND buffers of every model are rank 0's (the entry script seeds every process
+    alike, but nothing guarantees that a resumed checkpoint or an unseeded initialisation is identical everywhere; replicas
+    that start apart never meet again and nothing would report it).  One flat broadcast per model."""
+    if world <= 1:
+        return
+    for m in modules:
+        if m is None:
+            continue
+        ts = [t for t in list(m.parameters()) + list(m.buffers()) if t.is_floating_point()]
+        if not ts:
+            continue
+        flat = torch.cat([t.detach().reshape(-1).float() for t in ts])
+        dist.broadcast(flat, 0)
+        o = 0
+        with torch.no_grad():
+            for t in ts:
+                t.copy_(flat[o:o + t.numel()].view_as(t))
+                o += t.numel()
+        ints = [t for t in m.buffers() if not t.is_floating_point()]
+        for t in ints:                       # num_batches_tracked
+            dist.broadcast(t, 0)
+
+
+def decorrelate_dropout(model_gen, rank, world):
+    """Each rank draws its own dropout masks: the engine's Philox key is offset by the rank (identical keys would apply the
+    SAME masks to every rank's images, i.e. correlated noise across the global batch)."""
+    if world > 1 and hasattr(model_gen, "set_dropout_seed"):
+        model_gen.set_dropout_seed(1337 + 7919 * rank)
 
 
 def nan_guard(values, what):

@@ -192,3 +192,60 @@ def test_output_stride_8_matches_oracle():
     for n, a, b in zip(NAMES, mine, ref):
         assert a.shape == b.shape, n
         assert _rel(a, b) < 2e-4, (n, _rel(a, b))
+
+
+def test_nonfinite_activation_is_flagged_and_the_trainer_raises(tmp_path):
+    """A NaN pixel in the input: the engine's per-pass reduction over the BN statistics arena raises the device-side flag
+    (forward and backward), DeepLab.pop_nonfinite hands it over once, and Trainer_baseline turns it into the reference's
+    ValueError even when the loss itself stays finite."""
+    from oracle_ops import OracleOps
+    from uda_clr_amd.train_process import Trainer_baseline
+    m = _model().train()
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    m(x)
+    assert m.pop_nonfinite() is not None and not bool(m._engine_override.nonfinite or False)
+    xb = x.clone()
+    xb[1, 2, 10, 10] = float("nan")
+    m(xb)
+    assert bool(m.pop_nonfinite()) and m.pop_nonfinite() is None
+    tmap = (torch.rand(2, 2, 64, 64) > 0.5).float()
+    loader = [{"image": xb, "map": tmap, "boundary": torch.rand(2, 1, 64, 64), "img_name": ["a", "b"]}]
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = Trainer_baseline.Trainer(cuda=False, model_gen=m, optimizer_gen=opt, val_loader=loader, domain_loaderS=loader,
+                                  domain_loaderT=loader, out=str(tmp_path), max_epoch=1, stop_epoch=1, interval_validate=100,
+                                  batch_size=2, warmup_epoch=-1)
+    tr.ops = OracleOps()
+    # a loss that stays finite whatever the logits hold (on the HIP path the clamps already return finite values for NaN)
+    tr.ops.seg_loss = lambda o, b, mp, bd: torch.nan_to_num(o).mean() + torch.nan_to_num(b).mean()
+    with pytest.raises(ValueError, match="nan/inf"):
+        tr.train_epoch()
+
+
+def test_mc_fast_path_refuses_stale_activations():
+    """mc_dropout_logits reuses a training forward's activations only for the SAME unmodified input under unchanged parameters:
+    an in-place write to the input, note_params_changed() (what the trainers call after optimizer.step) or a mode change send
+    it down the plain-forward path instead of returning logits of the old state."""
+    m = _model().train()
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    calls = []
+    eng = m._engine_override
+    orig = eng.mc_forward
+    eng.mc_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    m(x)
+    m.mc_dropout_logits(x, passes=1, reps=2)
+    assert len(calls) == 1                                   # fresh: reused
+    m(x)
+    x.mul_(1.0)                                              # same address, new version
+    m.mc_dropout_logits(x, passes=1, reps=2)
+    assert len(calls) == 1
+    m(x)
+    m.note_params_changed()
+    m.mc_dropout_logits(x, passes=1, reps=2)
+    assert len(calls) == 1 and m._recent == []
+    m(x)
+    m.eval(); m.train()
+    m.mc_dropout_logits(x, passes=1, reps=2)
+    assert len(calls) == 1
+    m(x)
+    m.mc_dropout_logits(x, passes=1, reps=2)
+    assert len(calls) == 2

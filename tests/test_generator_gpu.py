@@ -267,3 +267,23 @@ def test_output_stride_8_forward_backward():
     print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
     assert not bad, list(bad.items())[:10]
     assert gmean < 4.0, gmean
+
+
+def test_nan_in_the_input_raises_in_the_trainer_although_the_clamps_swallow_it(tmp_path):
+    """The fused BN + activation prologues clamp with v_med3_f32, which maps NaN to a finite bound (torch.relu would propagate
+    it), so a diverged activation need not reach the loss.  The engine reduces every pass's BN-statistics arena to a
+    device-side non-finite flag; Trainer_baseline fetches it with its one host sync and raises the reference's ValueError
+    (Trainer_baseline.py:210-212 checks the loss for NaN)."""
+    from make_golden_inputs import synth_loader
+    from uda_clr_amd.train_process import Trainer_baseline
+    m = model_cases.seeded_model().to(DEV).train()
+    loader = synth_loader(1, 2, 64, 5)
+    m(loader[0]["image"].to(DEV))
+    assert not bool(m.pop_nonfinite())
+    loader[0]["image"][1, 2, 10, 10] = float("nan")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    tr = Trainer_baseline.Trainer(cuda=True, model_gen=m, optimizer_gen=opt, val_loader=loader, domain_loaderS=loader,
+                                  domain_loaderT=loader, out=str(tmp_path), max_epoch=1, stop_epoch=1, interval_validate=100,
+                                  batch_size=2, warmup_epoch=-1)
+    with pytest.raises(ValueError, match="nan"):
+        tr.train_epoch()

@@ -1,5 +1,8 @@
 // Loss, metric and category-prototype kernels of the training step (all HBM-bound streaming /
-// reduction kernels; LDS + wave reductions, two-stage deterministic sums in fp64).
+// reduction kernels; LDS + wave reductions).  Sums: per-thread and per-workgroup partials in fp64; the prototype sums are
+// combined by a second kernel in a fixed order (bit-reproducible), the seg-loss sums by fp64 atomicAdd across workgroups
+// (order-dependent in the last bits of the fp64 sum, i.e. ~1e-16 relative - far below the fp32 value the loss is rounded
+// to - but not bit-reproducible by construction); the pixel counts are integer atomics (exact).
 //   seg loss       BCELoss(sigmoid(o), map) + MSELoss(sigmoid(b), boundary)  Trainer_prototype_full.py:292-294
 //   seg counts     dice_coeff_2label / pixel_acc ingredients                  utils/metrics.py:118-168
 //   mc stats       std over T of sigmoid(x/2), mean over T of sigmoid(x)      utils/Utils.py:164-168

@@ -135,6 +135,13 @@ class GeneratorEngine:
         self.dils = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
         self.seed = seed
         self.rng_offset = 0
+        # device-side "something was NaN / Inf" flag of the passes since the last pop_nonfinite(): the fused BN + activation
+        # prologues clamp with v_med3_f32, which returns a finite bound for a NaN operand (relu(NaN) = 0 where torch propagates
+        # NaN), so a diverged activation would not reach the loss.  Every conv output and every BN-backward operand passes
+        # through a per-channel sum in the statistics arena, so ONE reduction over that arena per pass sees any NaN / Inf;
+        # the trainers fetch the flag with their single host sync and raise like the reference's NaN checks
+        # (Trainer_prototype_full.py:296-299).
+        self.nonfinite = None
         # channels that receive BN statistics in one forward (stem, blocks, ASPP, decoder)
         if backbone == "mobilenet":
             self.blocks = block_plan(output_stride)
@@ -153,6 +160,16 @@ class GeneratorEngine:
         self.bn_channels = n + 5 * 256 + 256 + 48 + 256 + 256 + 305
 
     # ------------------------------------------------------------------ small helpers
+    def _check_arena(self, ctx):
+        if ctx.arena is not None:
+            bad = ~torch.isfinite(ctx.arena.buf.sum())
+            self.nonfinite = bad if self.nonfinite is None else (self.nonfinite | bad)
+
+    def pop_nonfinite(self):
+        """0-dim bool tensor (or None): a NaN / Inf went through a BN statistic since the last call."""
+        f, self.nonfinite = self.nonfinite, None
+        return f
+
     @staticmethod
     def _empty(x, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=x.device)
@@ -574,6 +591,7 @@ class GeneratorEngine:
         if ctx.tn_repeat:
             S["dec"] = dict(lo=lo, y0=None)
             ctx.dims = (N, Hin, Win, H16, W16, H4, W4)
+            self._check_arena(ctx)
             ctx.arena, ctx.nbt = None, []
             return None, ctx
         K.bn_apply(lo, xf[:, 256:304], None)
@@ -611,6 +629,7 @@ class GeneratorEngine:
         if ctx.nbt:
             torch._foreach_add_(ctx.nbt, 1)          # num_batches_tracked of all 61 BNs in one launch
             ctx.nbt = []
+        self._check_arena(ctx)
         ctx.arena = None
         outs = (x1, x2, nchw_view(feature, N, H16, W16), nchw_view(xf[:, :304], N, H4, W4),
                 nchw_view(xf[:, :305], N, H4, W4), nchw_view(x1b, N, H4, W4),
@@ -688,6 +707,7 @@ class GeneratorEngine:
             x1b = self._buf(x, reps * P4, 2)
             K.conv(sa, self._w(ctx, "decoder.last_conv.3.weight", "ohwi"), 1, 1, x1b, bias=params["decoder.last_conv.3.bias"])
             K.head_upsample_fwd(x1b, N2, H4, W4, out[ps * N2:(ps + 1) * N2])
+            self._check_arena(ctx)
             ctx.arena = None
             if ctx.nbt:      # the three stochastic BNs of this pass
                 torch._foreach_add_(ctx.nbt, 1)
@@ -877,4 +897,6 @@ class GeneratorEngine:
             self._mobilenet_backward(ctx, G, d_a, d_low)
         else:
             self._resnet_backward(ctx, G, d_a, d_low)
+        self._check_arena(ctx)
+        ctx.arena = None
         return G

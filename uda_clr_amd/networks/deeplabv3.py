@@ -66,7 +66,8 @@ class DeepLab(Holder):
         self.aspp = build_aspp(backbone, output_stride, BatchNorm)
         self.decoder = build_decoder(num_classes, backbone, method, BatchNorm)
         self._engine = None
-        self._recent = []                 # (input data_ptr, shape, engine ctx) of the last training forwards
+        self._recent = []                 # (input data_ptr, shape, input version, generation, engine ctx) of the last training forwards
+        self._generation = 0              # bumped whenever parameters / buffers / mode may have changed (note_params_changed)
         self._engine_override = None      # tests only: an engine bound to their torch kernel spec
         self._next_masks = None           # tests only: injected dropout keep-masks for one forward
         if freeze_bn:
@@ -103,18 +104,39 @@ class DeepLab(Holder):
         if self._engine is not None:
             self._engine.seed = self._dropout_seed
 
+    def pop_nonfinite(self):
+        """0-dim bool device tensor (or None if no pass ran): a NaN / Inf went through a BatchNorm statistic of a forward or
+        backward pass since the last call (see GeneratorEngine.nonfinite).  The trainers fold it into their one host sync."""
+        eng = self._engine_override or self._engine
+        return None if eng is None else eng.pop_nonfinite()
+
     def _remember(self, x, ectx):
-        self._recent = [(x.data_ptr(), tuple(x.shape), ectx)] + self._recent[:1]
+        self._recent = [(x.data_ptr(), tuple(x.shape), x._version, self._generation, ectx)] + self._recent[:1]
 
     def _forget(self, ectx):
-        self._recent = [r for r in self._recent if r[2] is not ectx]
+        self._recent = [r for r in self._recent if r[4] is not ectx]
+
+    def note_params_changed(self):
+        """Invalidate the activations kept for ``mc_dropout_logits``: call after anything that changes parameters or buffers
+        outside this module's sight (torch's fused optimizer steps do not bump tensor versions).  The bundled trainers call
+        it after every optimizer step; ``train()`` / ``eval()`` / ``load_state_dict`` do it themselves."""
+        self._generation += 1
+        self._recent = []
+
+    def train(self, mode=True):
+        self.note_params_changed()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.note_params_changed()
+        return super().load_state_dict(*args, **kwargs)
 
     def mc_dropout_logits(self, x, passes=4, reps=2, masks=None):
         """Segmentation logits of ``passes`` no-grad training-mode forwards on ``x.repeat(reps,1,1,1)``
         (Trainer_prototype_full.py:358-368: T = passes*reps stochastic predictions per image), as one
-        [passes*reps*N, 2, H, W] tensor.  When ``x`` is the input of a recent grad-mode training forward
-        of this module (and no parameter changed since), the deterministic pre-dropout activations of
-        that forward are reused and only the dropout-dependent tail is recomputed
+        [passes*reps*N, 2, H, W] tensor.  When ``x`` is the unmodified input of a recent grad-mode training
+        forward of this module and ``note_params_changed`` has not been called since (the trainers call it after
+        every optimizer step), the deterministic pre-dropout activations of that forward are reused and only the dropout-dependent tail is recomputed
         (``GeneratorEngine.mc_forward``); otherwise the passes run as plain forwards."""
         assert self.training, "stochastic passes need training mode (dropout + batch statistics)"
         if self.transnorm and reps == 2:
@@ -125,8 +147,10 @@ class DeepLab(Holder):
                 engine = self._engine_for(x)
                 _, ectx = engine.forward(self._flat_state(), x.contiguous().float(), True, True, None, repeat_prefix=True)
                 return engine.mc_forward(ectx, reps, passes, masks=masks)
-        for ptr, shape, ectx in ([] if self.transnorm else self._recent):
-            if ptr == x.data_ptr() and shape == tuple(x.shape):
+        for ptr, shape, version, generation, ectx in ([] if self.transnorm else self._recent):
+            # the SAME tensor (address, shape, not written since) under the SAME parameters (no optimizer step, mode change or
+            # state load since): anything else falls through to plain forwards
+            if ptr == x.data_ptr() and shape == tuple(x.shape) and version == x._version and generation == self._generation:
                 with torch.no_grad():
                     return self._engine_for(x).mc_forward(ectx, reps, passes, masks=masks)
         outs = []

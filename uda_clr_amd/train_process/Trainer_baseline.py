@@ -109,8 +109,9 @@ class Trainer(TrainerBase):
             if self._reducer is not None:
                 self._reducer.all_reduce_mean()
             self.optim_gen.step()
-            loss_seg_data = loss_seg.item()                 # the step's single host sync
-            nan_guard([loss_seg_data], 'loss')
+            if hasattr(self.model_gen, 'note_params_changed'):
+                self.model_gen.note_params_changed()       # activations kept for the MC passes are stale now
+            loss_seg_data = self._fetch([loss_seg])[0]      # the step's single host sync (loss + non-finite flag)
             self.running_seg_loss += loss_seg_data
             self.writer.add_scalar('train_gen/loss_seg', loss_seg_data, self.iteration)
             self._log_row([self.epoch, self.iteration, loss_seg_data] + [''] * 5 + [self.elapsed()])

@@ -266,6 +266,8 @@ class Trainer(TrainerBase):
         if self._reducers is not None:
             self._reducers[0].all_reduce_mean()
         self.optim_gen.step()
+        if hasattr(self.model_gen, 'note_params_changed'):
+            self.model_gen.note_params_changed()       # activations kept for the MC passes are stale now
         # ---- discriminators on detached generator outputs (:471-517)
         self._set_requires_grad((gen,), False)
         oS, boundaryS = oS.detach(), boundaryS.detach()
@@ -284,9 +286,7 @@ class Trainer(TrainerBase):
         scalars += [loss_D_same.detach(), loss_D_diff.detach()]
         if intra_loss is not None:
             scalars += [intra_loss.detach(), inter_loss.detach()]
-        vals = torch.stack([s.float().reshape(()) for s in scalars]).tolist()                # the single host sync
-        nan_guard(vals, 'loss')
-        return vals
+        return self._fetch(scalars)                                                          # the single host sync
 
     # ------------------------------------------------------------------ one epoch
     def train_epoch(self):

@@ -262,6 +262,20 @@ class TrainerBase(object):
         out.update(image=image, map=mp, boundary=bd)
         return out
 
+    def _fetch(self, scalars):
+        """The step's single host sync: the loss scalars plus the generator's device-side non-finite flag (a NaN / Inf that
+        went through any BatchNorm statistic of the step's passes; the fused activation clamps do not propagate NaN, see
+        GeneratorEngine.nonfinite).  Raises ValueError like the reference's NaN checks (Trainer_prototype_full.py:296-299)."""
+        flag = self.model_gen.pop_nonfinite() if hasattr(self.model_gen, "pop_nonfinite") else None
+        ts = [s.detach().float().reshape(()) for s in scalars]
+        if flag is not None:
+            ts.append(flag.float().reshape(()))
+        vals = torch.stack(ts).tolist()
+        if flag is not None and vals.pop() > 0:
+            raise ValueError('activations or gradients are nan/inf while training')
+        nan_guard(vals, 'loss')
+        return vals
+
     def _log_row(self, fields):
         if self.rank != 0:
             return

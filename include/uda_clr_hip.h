@@ -310,6 +310,28 @@ int uda_photometric_u8(uint8_t* image_hwc, int B, int H, int W, const int* sp_po
 int uda_elastic_warp(const uint8_t* image_hwc, const uint8_t* label, const double* dx, const double* dy, const uint8_t* apply,
                      int B, int H, int W, uint8_t* image_out, uint8_t* label_out, void* stream);
 
+/* Trainer_prototype_full.py:335-355, 378-398 (EMA of the eight centroids, gradient through the current term only) + :428-444
+ * (intra = sum_k MSE(src_k, tgt_k), inter = MSE(src_1, src_3) + MSE(src_0, src_2)) on two [4][C] centroid matrices in one
+ * launch: new = prev ? keep * prev + decay * cur : cur (keep = 1 - decay as the caller's double expression rounds it);
+ * losses2 = (intra, inter).  prev_* may be null (first use).
+ * uda_proto_align_bwd: d intra / d cur_src = g * w_src * 2 (new_src - new_tgt) / C, d cur_tgt = -g * w_tgt * (...). */
+int uda_proto_align_fwd(const float* cur_src, const float* cur_tgt, const float* prev_src, const float* prev_tgt, float keep,
+                        float decay, int C, float* new_src, float* new_tgt, float* losses2, void* stream);
+int uda_proto_align_bwd(const float* new_src, const float* new_tgt, const float* g_intra, float w_src, float w_tgt, int C,
+                        float* d_cur_src, float* d_cur_tgt, void* stream);
+/* Trainer_prototype_full.py:456-458, 479-513: scale * (BCEWithLogitsLoss(d1, label) + BCEWithLogitsLoss(d2, label)) on the two
+ * patch-discriminator outputs (n1, n2 elements), forward in one launch, both gradients in one launch (g: device scalar). */
+int uda_adv_loss_fwd(const float* d1, int n1, const float* d2, int n2, float label, float scale, float* loss, void* stream);
+int uda_adv_loss_bwd(const float* d1, int n1, const float* d2, int n2, float label, float scale, const float* g, float* g1,
+                     float* g2, void* stream);
+/* Trainer_prototype_full.py:452-454: the first discriminator layer fed by generator LOGITS (NCHW): z = s2d(pre(x)),
+ * pre_op 1 = sigmoid(x) (boundary branch), 2 = -sigmoid(x) * log(sigmoid(x) + 1e-7) (uncertainty map); the adjoint routes
+ * dz back to the logits and multiplies by pre'(x).  No full-resolution intermediate map is materialised. */
+int uda_adv_s2d_fwd(const float* logits_nchw, int N, int C, int H, int W, int pre_op, float* z, int64_t ld_z, int Hz, int Wz,
+                    void* stream);
+int uda_adv_s2d_bwd(const float* dz, int64_t ld_z, int Hz, int Wz, const float* logits_nchw, int N, int C, int H, int W,
+                    int pre_op, float* d_logits_nchw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -991,3 +991,68 @@ CASES += [
     ("postprocess 2 x 2 x 200 x 136 vs scipy (ragged tiles)", case_postprocess(2, 200, 136, seed=62)),
     ("postprocess 1 x 2 x 512 x 512 vs scipy", case_postprocess(1, 512, 512, seed=63)),
 ]
+
+
+# ---------------------------------------------------------------- fused alignment / adversarial glue
+def case_proto_align(C, prev, seed=71):
+    """uda_proto_align_fwd / bwd (EMA of the eight centroids + intra / inter and the gradient through the current term)."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        cs, ct = torch.randn(4, C, generator=g), torch.randn(4, C, generator=g)
+        ps, pt = (torch.randn(4, C, generator=g), torch.randn(4, C, generator=g)) if prev else (None, None)
+        d = lambda t: None if t is None else t.to(dev)
+        ns_r, nt_r, l_r = SPEC.proto_align_fwd(cs, ct, ps, pt, 0.9)
+        ns_h, nt_h, l_h = K.proto_align_fwd(cs.to(dev), ct.to(dev), d(ps), d(pt), 0.9)
+        gi = torch.tensor([0.37])
+        w = 0.9 if prev else 1.0
+        a_r, b_r = SPEC.proto_align_bwd(ns_r, nt_r, gi, w, w)
+        a_h, b_h = K.proto_align_bwd(ns_h, nt_h, gi.to(dev), w, w)
+        exact = torch.equal(ns_h.cpu(), ns_r) and torch.equal(nt_h.cpu(), nt_r)      # the EMA itself: the reference's expression, bit for bit
+        return max(rel(l_h, l_r), rel(a_h, a_r), rel(b_h, b_r), 0.0 if exact else 1.0), 2e-6
+    return run
+
+
+def case_adv_loss(n1, n2, label, scale, seed=72):
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        d1, d2 = 3 * torch.randn(n1, generator=g), 3 * torch.randn(n2, generator=g)
+        d1[:4] = torch.tensor([40., -40., 100., -100.])
+        l_r = SPEC.adv_loss_fwd(d1, d2, label, scale)
+        l_h = K.adv_loss_fwd(d1.to(dev), d2.to(dev), label, scale)
+        gi = torch.tensor([1.7])
+        a_r, b_r = SPEC.adv_loss_bwd(d1, d2, label, scale, gi)
+        a_h, b_h = K.adv_loss_bwd(d1.to(dev), d2.to(dev), label, scale, gi.to(dev))
+        return max(rel(l_h, l_r), rel(a_h, a_r), rel(b_h, b_r)), 2e-6
+    return run
+
+
+def case_adv_s2d(N, C, H, W, op, seed=73):
+    """First discriminator layer fed by logits: z = s2d(sigmoid | uncertainty map) and its adjoint incl. the map's derivative."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        x = 3 * torch.randn(N, C, H, W, generator=g)
+        x[0, 0, 0, :4] = torch.tensor([30., -30., 90., -90.])          # saturated sigmoids: log(s + 1e-7) at s = 0 and s = 1
+        Hz, Wz = (H + 5) // 2, (W + 5) // 2
+        z_r, z_h = torch.empty(N * Hz * Wz, 4 * C), torch.empty(N * Hz * Wz, 4 * C, device=dev)
+        SPEC.adv_s2d_fwd(x, op, z_r)
+        K.adv_s2d_fwd(x.to(dev), op, z_h)
+        dz = torch.randn(N * Hz * Wz, 4 * C, generator=g)
+        d_r, d_h = torch.empty_like(x), torch.empty(N, C, H, W, device=dev)
+        SPEC.adv_s2d_bwd(dz, x, op, d_r)
+        K.adv_s2d_bwd(dz.to(dev), x.to(dev), op, d_h)
+        return max(rel(z_h, z_r), rel(d_h, d_r)), 5e-6
+    return run
+
+
+CASES += [
+    ("proto_align C=305 first use", case_proto_align(305, False)),
+    ("proto_align C=305 EMA", case_proto_align(305, True)),
+    ("proto_align C=7 EMA", case_proto_align(7, True)),
+    ("adv_loss 2x17x17 label 1 scale 0.01", case_adv_loss(578, 578, 1.0, 0.01)),
+    ("adv_loss label 0 scale 1 ragged", case_adv_loss(300, 77, 0.0, 1.0)),
+    ("adv_s2d sigmoid C=1 64x64", case_adv_s2d(2, 1, 64, 64, 1)),
+    ("adv_s2d entropy C=2 50x46", case_adv_s2d(2, 2, 50, 46, 2)),
+]

@@ -267,6 +267,24 @@ class SpecKernels:
         out[:, :, :vh, :vw] = gp[:, :, 2:2 + vh, 2:2 + vw]
         dst.copy_(out if nchw else out.permute(0, 2, 3, 1).reshape(N * Hs * Ws, Cc))
 
+    @staticmethod
+    def _adv_pre(x, op):
+        s = torch.sigmoid(x)
+        return s if op == 1 else -1.0 * s * torch.log(s + 1e-7)
+
+    def adv_s2d_fwd(self, logits, pre_op, z):
+        N, Cc, H, W = logits.shape
+        self.s2d_fwd(self._adv_pre(logits, pre_op), True, N, H, W, Cc, H, W, 1.0, z)
+
+    def adv_s2d_bwd(self, dz, logits, pre_op, d_logits):
+        N, Cc, H, W = logits.shape
+        g = torch.empty_like(logits)
+        self.s2d_bwd(dz, None, 1.0, N, H, W, Cc, H, W, g, True)
+        with torch.enable_grad():
+            x = logits.detach().clone().requires_grad_(True)
+            self._adv_pre(x, pre_op).backward(g)
+        d_logits.copy_(x.grad)
+
     # ------------------------------------------------------------------ batch norm pieces
     def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps,
                     scale, shift, mean, invstd):
@@ -531,6 +549,25 @@ class SpecKernels:
         if want_dw:
             return (feat.double() @ coef.t() + extra).float()
         return None
+
+    def proto_align_fwd(self, cur_src, cur_tgt, prev_src, prev_tgt, decay):
+        new_src = cur_src.clone() if prev_src is None else (1 - decay) * prev_src + decay * cur_src
+        new_tgt = cur_tgt.clone() if prev_tgt is None else (1 - decay) * prev_tgt + decay * cur_tgt
+        intra = sum(F.mse_loss(new_src[k], new_tgt[k]) for k in range(4))
+        inter = F.mse_loss(new_src[1], new_src[3]) + F.mse_loss(new_src[0], new_src[2])
+        return new_src, new_tgt, torch.stack([intra, inter])
+
+    def proto_align_bwd(self, new_src, new_tgt, g, w_src, w_tgt):
+        v = g.reshape(()) * 2.0 * (new_src - new_tgt) / new_src.shape[1]
+        return w_src * v, -w_tgt * v
+
+    def adv_loss_fwd(self, d1, d2, label, scale):
+        f = F.binary_cross_entropy_with_logits
+        return (scale * (f(d1, torch.full_like(d1, label)) + f(d2, torch.full_like(d2, label)))).reshape(1)
+
+    def adv_loss_bwd(self, d1, d2, label, scale, g):
+        gs = g.reshape(()) * scale
+        return (torch.sigmoid(d1) - label) * gs / d1.numel(), (torch.sigmoid(d2) - label) * gs / d2.numel()
 
     def feat_dot4(self, feat, coef):
         Cc = feat.shape[1]

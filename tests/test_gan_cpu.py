@@ -66,3 +66,23 @@ def test_cpu_input_fails_loudly():
     d = GAN.BoundaryDiscriminator()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         d(torch.zeros(2, 1, 32, 32))
+
+
+@pytest.mark.parametrize("kind,pre", [("BoundaryDiscriminator", "sigmoid"), ("UncertaintyDiscriminator", "entropy")])
+def test_fused_logit_maps_match_the_reference_expressions(kind, pre):
+    """forward(logits, pre=...) == the discriminator on sigmoid(logits) / on -sigmoid * log(sigmoid + 1e-7)
+    (Trainer_prototype_full.py:452-454), values and gradients into the logits and the weights."""
+    mine, ref = _pair(kind)
+    cin = ref.conv1.weight.shape[1]
+    x = 2.0 * torch.randn(2, cin, 48, 48, generator=torch.Generator().manual_seed(7))     # a seed without a LeakyReLU pre-activation within rounding of 0
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = mine(xa, pre=pre)
+    s = torch.sigmoid(xb)
+    yb = ref(s if pre == "sigmoid" else -1.0 * s * torch.log(s + 1e-7))
+    assert _rel(ya, yb) < 1e-5
+    g = torch.randn(yb.shape, generator=torch.Generator().manual_seed(2))
+    ya.backward(g)
+    yb.backward(g)
+    assert _rel(xa.grad, xb.grad) < 1e-4
+    for i in range(1, 6):
+        assert _rel(getattr(mine, "conv%d" % i).weight.grad, getattr(ref, "conv%d" % i).weight.grad) < 1e-4, i

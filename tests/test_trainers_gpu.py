@@ -131,3 +131,51 @@ def test_trainer_prototype_full_hip_matches_reference_rows(golden_dir, tmp_path)
     np.testing.assert_allclose(rows[0], ref[0], rtol=1e-3)                # first iteration: forward-only quantities, incl. intra / inter
     np.testing.assert_allclose(rows[:, :4], ref[:, :4], rtol=5e-3)        # after an Adam step (measured 7e-4 on seg, 1e-5 on the adversarial terms)
     np.testing.assert_allclose(rows[:, 4:], ref[:, 4:], rtol=6e-2)        # prototype distances after the step (B = 2: measured 3.7e-2)
+
+
+def test_flat_adam_matches_torch_adam_and_keeps_the_checkpoint_layout():
+    """uda_clr_amd.optim.FlatAdam (one uda_adam_step launch per group on flat buffers) against torch.optim.Adam on the same
+    gradients: parameters after 4 steps (incl. an LR change through param_groups, as the trainers' LR rule does), the
+    state_dict layout the checkpoints store, and resuming from a torch state_dict."""
+    from uda_clr_amd.optim import FlatAdam, take_over
+    g = torch.Generator().manual_seed(0)
+    shapes = [(32, 3, 3, 3), (32,), (7,), (305, 2, 1, 1), (1,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    oa = take_over(torch.optim.Adam(pa, lr=1e-3, betas=(0.9, 0.99)))
+    ob = torch.optim.Adam(pb, lr=1e-3, betas=(0.9, 0.99))
+    assert isinstance(oa, FlatAdam)
+    for it in range(4):
+        if it == 2:
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    grp["lr"] = 2e-4
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).to(DEV)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7), (x - y).abs().max()
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0]["lr"] == sb["param_groups"][0]["lr"] and list(sa["state"].keys()) == list(sb["state"].keys())
+    for k in sb["state"]:
+        assert set(sa["state"][k]) == set(sb["state"][k]) == {"step", "exp_avg", "exp_avg_sq"}
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 4.0
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+    # resume: a fresh torch Adam loads the checkpointed state, FlatAdam takes it over and continues identically
+    pc = mk()
+    with torch.no_grad():
+        for x, y in zip(pc, pb):
+            x.copy_(y)
+    inner = torch.optim.Adam(pc, lr=1e-3, betas=(0.9, 0.99))
+    inner.load_state_dict(sb)
+    oc = take_over(inner)
+    for x, y in zip(pc, pb):
+        gr = torch.randn(x.shape, generator=g).to(DEV)
+        x.grad, y.grad = gr.clone(), gr.clone()
+    oc.step()
+    ob.step()
+    for x, y in zip(pc, pb):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+    assert float(oc.state_dict()["state"][0]["step"]) == 5.0

@@ -17,7 +17,25 @@ struct S2dArgs {
     int N, Hs, Ws, C, vh, vw, Hz, Wz;
     int nchw;             // the un-s2d side (src forward / dst backward) is NCHW
     float slope;
+    // first layer fed by generator LOGITS (Trainer_prototype_full.py:452-454, 479-487): 0 = plain values,
+    // 1 = sigmoid(x), 2 = uncertainty map -sigmoid(x) * log(sigmoid(x) + 1e-7).  Backward multiplies the routed gradient by the
+    // derivative at the logits `pre_x` (NCHW, the forward's source).
+    int pre_op;
+    const float* pre_x;
 };
+
+#define ADV_SMOOTH 1e-7f
+__device__ __forceinline__ float adv_pre(float x, int op) {
+    if (op == 0) return x;
+    const float s = 1.f / (1.f + expf(-x));
+    return op == 1 ? s : -1.f * s * logf(s + ADV_SMOOTH);
+}
+__device__ __forceinline__ float adv_pre_grad(float x, int op) {          // d adv_pre / dx
+    if (op == 0) return 1.f;
+    const float s = 1.f / (1.f + expf(-x));
+    const float ds = s * (1.f - s);
+    return op == 1 ? ds : -(logf(s + ADV_SMOOTH) + s / (s + ADV_SMOOTH)) * ds;
+}
 
 // forward: one thread per (n, i, j, a, b, c)
 __global__ __launch_bounds__(256) void s2d_fwd_kernel(S2dArgs p) {
@@ -33,6 +51,7 @@ __global__ __launch_bounds__(256) void s2d_fwd_kernel(S2dArgs p) {
         if (h >= 0 && h < p.vh && w >= 0 && w < p.vw) {
             v = p.nchw ? p.src[(((int64_t)n * p.C + c) * p.Hs + h) * p.Ws + w]
                        : p.src[(((int64_t)n * p.Hs + h) * p.Ws + w) * p.ld_src + c];
+            if (p.pre_op) v = adv_pre(v, p.pre_op);
             v = v > 0.f ? v : v * p.slope;
         }
         p.dst[pz * p.ld_dst + q] = v;
@@ -79,6 +98,7 @@ __global__ __launch_bounds__(256) void s2d_bwd_kernel(S2dArgs p) {
             const int q = ((((h + 2) & 1) << 1) | ((w + 2) & 1)) * p.C + c;
             g = p.src[pz * p.ld_src + q];
             if (p.zsign && !(p.zsign[pz * p.ld_src + q] > 0.f)) g *= p.slope;
+            if (p.pre_op) g *= adv_pre_grad(p.pre_x[e], p.pre_op);        // nchw only (checked by the entry point): e indexes the logits
         }
         if (p.nchw) p.dst[e] = g;
         else p.dst[(((int64_t)n * p.Hs + h) * p.Ws + w) * p.ld_dst + c] = g;
@@ -122,6 +142,7 @@ extern "C" int uda_s2d_fwd(const float* src, int64_t ld_src, int nchw_in, int N,
     S2dArgs p;
     p.src = src; p.ld_src = ld_src; p.zsign = nullptr; p.dst = z; p.ld_dst = ld_z;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.C = C; p.vh = valid_h; p.vw = valid_w; p.Hz = Hz; p.Wz = Wz; p.nchw = nchw_in; p.slope = slope;
+    p.pre_op = 0; p.pre_x = nullptr;
     const bool v4 = !nchw_in && C % 4 == 0 && ld_src % 4 == 0 && ld_z % 4 == 0 && uda_aligned16(src) && uda_aligned16(z);
     const int64_t total = (int64_t)N * Hz * Wz * (v4 ? C : 4 * C);
     const int grid = (int)(uda_cdiv(total, 256) > 16384 ? 16384 : uda_cdiv(total, 256));
@@ -138,6 +159,7 @@ extern "C" int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, i
     S2dArgs p;
     p.src = dz; p.ld_src = ld_z; p.zsign = z_sign; p.dst = dst; p.ld_dst = ld_dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.C = C; p.vh = valid_h; p.vw = valid_w; p.Hz = Hz; p.Wz = Wz; p.nchw = nchw_out; p.slope = slope;
+    p.pre_op = 0; p.pre_x = nullptr;
     const bool v4 = !nchw_out && C % 4 == 0 && ld_z % 4 == 0 && ld_dst % 4 == 0 && uda_aligned16(dz) && uda_aligned16(dst) &&
                     (!z_sign || uda_aligned16(z_sign));
     const int64_t total = (int64_t)N * Hs * Ws * (v4 ? C / 4 : C);
@@ -145,6 +167,39 @@ extern "C" int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, i
     if (v4) hipLaunchKernelGGL(s2d_bwd4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(s2d_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     UDA_LAUNCH_CHECK("s2d_bwd");
+    return 0;
+}
+
+// First discriminator layer fed by generator logits: z = s2d(pre(logits)) and its adjoint d logits = route(dz) * pre'(logits),
+// pre = sigmoid (boundary branch) or the uncertainty map (Trainer_prototype_full.py:452-454); replaces the elementwise
+// sigmoid / log / mul chain and its autograd backward on the full-resolution maps.
+extern "C" int uda_adv_s2d_fwd(const float* logits_nchw, int N, int C, int H, int W, int pre_op, float* z, int64_t ld_z, int Hz, int Wz,
+                               void* stream) {
+    if (int e = s2d_check("uda_adv_s2d_fwd", logits_nchw, z, N, H, W, C, H, W, Hz, Wz)) return e;
+    UDA_REQUIRE(ld_z >= 4 * C && (pre_op == 1 || pre_op == 2), "uda_adv_s2d_fwd: bad leading dimension or pre_op");
+    S2dArgs p;
+    p.src = logits_nchw; p.ld_src = 0; p.zsign = nullptr; p.dst = z; p.ld_dst = ld_z;
+    p.N = N; p.Hs = H; p.Ws = W; p.C = C; p.vh = H; p.vw = W; p.Hz = Hz; p.Wz = Wz; p.nchw = 1; p.slope = 1.f;
+    p.pre_op = pre_op; p.pre_x = nullptr;
+    const int64_t total = (int64_t)N * Hz * Wz * 4 * C;
+    const int grid = (int)(uda_cdiv(total, 256) > 16384 ? 16384 : uda_cdiv(total, 256));
+    hipLaunchKernelGGL(s2d_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    UDA_LAUNCH_CHECK("adv_s2d_fwd");
+    return 0;
+}
+
+extern "C" int uda_adv_s2d_bwd(const float* dz, int64_t ld_z, int Hz, int Wz, const float* logits_nchw, int N, int C, int H, int W,
+                               int pre_op, float* d_logits_nchw, void* stream) {
+    if (int e = s2d_check("uda_adv_s2d_bwd", dz, d_logits_nchw, N, H, W, C, H, W, Hz, Wz)) return e;
+    UDA_REQUIRE(ld_z >= 4 * C && logits_nchw && (pre_op == 1 || pre_op == 2), "uda_adv_s2d_bwd: bad args");
+    S2dArgs p;
+    p.src = dz; p.ld_src = ld_z; p.zsign = nullptr; p.dst = d_logits_nchw; p.ld_dst = 0;
+    p.N = N; p.Hs = H; p.Ws = W; p.C = C; p.vh = H; p.vw = W; p.Hz = Hz; p.Wz = Wz; p.nchw = 1; p.slope = 1.f;
+    p.pre_op = pre_op; p.pre_x = logits_nchw;
+    const int64_t total = (int64_t)N * H * W * C;
+    const int grid = (int)(uda_cdiv(total, 256) > 16384 ? 16384 : uda_cdiv(total, 256));
+    hipLaunchKernelGGL(s2d_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    UDA_LAUNCH_CHECK("adv_s2d_bwd");
     return 0;
 }
 

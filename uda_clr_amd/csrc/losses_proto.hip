@@ -443,3 +443,117 @@ extern "C" int uda_adam_step(float* params, const float* grads, float* exp_avg, 
     UDA_LAUNCH_CHECK("adam");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------ prototype EMA + alignment losses
+// Trainer_prototype_full.py:335-355, 378-398 (EMA of the eight centroids, gradient only through the current term - quirk Q4)
+// and :428-444 (intra = sum_k MSE(src_k, tgt_k); inter = MSE(src_1, src_3) + MSE(src_0, src_2), logged only), as ONE launch on
+// the two [4][C] centroid matrices (k = cup_obj, disc_obj, cup_bck, disc_bck):
+//     new = has_prev ? keep * prev + decay * cur : cur                (per domain; keep = 1 - decay evaluated by the caller in
+//                                                                      double like the reference's Python expression)
+//     losses[0] = sum_k mean_c (new_src[k][c] - new_tgt[k][c])^2,   losses[1] = mean_c (s1 - s3)^2 + mean_c (s0 - s2)^2
+// Backward of losses[0] w.r.t. the CURRENT centroids: d cur_src = g * w_src * 2 (new_src - new_tgt) / C, d cur_tgt = -(...) with
+// w = decay (or 1 on first use).  One workgroup; fp64 block sums.
+__global__ __launch_bounds__(256) void proto_align_fwd_kernel(const float* __restrict__ cur_src, const float* __restrict__ cur_tgt,
+                                                              const float* __restrict__ prev_src, const float* __restrict__ prev_tgt,
+                                                              float keep, float decay, int C, float* __restrict__ new_src,
+                                                              float* __restrict__ new_tgt, float* __restrict__ losses) {
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    double intra = 0.0, inter = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s[4], t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float cs = cur_src[k * C + c], ct = cur_tgt[k * C + c];
+            // (1-decay) * stored + decay * current (Trainer_prototype_full.py:348-351), two products then one add, no fma
+            s[k] = prev_src ? keep * prev_src[k * C + c] + decay * cs : cs;
+            t[k] = prev_tgt ? keep * prev_tgt[k * C + c] + decay * ct : ct;
+            new_src[k * C + c] = s[k];
+            new_tgt[k * C + c] = t[k];
+            const float d = s[k] - t[k];
+            intra += (double)(d * d);
+        }
+        const float d13 = s[1] - s[3], d02 = s[0] - s[2];
+        inter += (double)(d13 * d13) + (double)(d02 * d02);
+    }
+    const double a = block_sum(intra, red);
+    const double b = block_sum(inter, red);
+    if (threadIdx.x == 0) {
+        losses[0] = (float)(a / (double)C);
+        losses[1] = (float)(b / (double)C);
+    }
+}
+
+__global__ __launch_bounds__(256) void proto_align_bwd_kernel(const float* __restrict__ new_src, const float* __restrict__ new_tgt,
+                                                              const float* __restrict__ g, float w_src, float w_tgt, int C,
+                                                              float* __restrict__ d_cur_src, float* __restrict__ d_cur_tgt) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 4 * C) return;
+    const float v = g[0] * 2.f * (new_src[e] - new_tgt[e]) / (float)C;
+    d_cur_src[e] = w_src * v;
+    d_cur_tgt[e] = -w_tgt * v;
+}
+
+extern "C" int uda_proto_align_fwd(const float* cur_src, const float* cur_tgt, const float* prev_src, const float* prev_tgt,
+                                   float keep, float decay, int C, float* new_src, float* new_tgt, float* losses2, void* stream) {
+    UDA_REQUIRE(cur_src && cur_tgt && new_src && new_tgt && losses2 && C > 0, "uda_proto_align_fwd: bad args");
+    hipLaunchKernelGGL(proto_align_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cur_src, cur_tgt, prev_src, prev_tgt, keep,
+                       decay, C, new_src, new_tgt, losses2);
+    UDA_LAUNCH_CHECK("proto_align_fwd");
+    return 0;
+}
+
+extern "C" int uda_proto_align_bwd(const float* new_src, const float* new_tgt, const float* g_intra, float w_src, float w_tgt, int C,
+                                   float* d_cur_src, float* d_cur_tgt, void* stream) {
+    UDA_REQUIRE(new_src && new_tgt && g_intra && d_cur_src && d_cur_tgt && C > 0, "uda_proto_align_bwd: bad args");
+    hipLaunchKernelGGL(proto_align_bwd_kernel, dim3(uda_cdiv(4 * C, 256)), dim3(256), 0, (hipStream_t)stream, new_src, new_tgt, g_intra,
+                       w_src, w_tgt, C, d_cur_src, d_cur_tgt);
+    UDA_LAUNCH_CHECK("proto_align_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ adversarial loss on the patch logits
+// scale * (BCEWithLogits(d1, label) + BCEWithLogits(d2, label)), both 'mean' (Trainer_prototype_full.py:456-458 with scale 0.01 and
+// label 1; :479-513 with scale 1 and labels 1 / 0), on the two small [N,1,Ho,Wo] discriminator outputs: one launch forward
+// (numerically as torch: max(x,0) - x*y + log1p(exp(-|x|))), one launch for both gradients (sigmoid(x) - y) * scale * g / n.
+__global__ __launch_bounds__(256) void adv_loss_fwd_kernel(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
+                                                           float label, float scale, float* __restrict__ loss) {
+    __shared__ double red[4];
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = threadIdx.x; e < n1; e += 256) {
+        const float x = d1[e];
+        s1 += (double)(fmaxf(x, 0.f) - x * label + log1pf(expf(-fabsf(x))));
+    }
+    for (int e = threadIdx.x; e < n2; e += 256) {
+        const float x = d2[e];
+        s2 += (double)(fmaxf(x, 0.f) - x * label + log1pf(expf(-fabsf(x))));
+    }
+    const double a = block_sum(s1, red);
+    const double b = block_sum(s2, red);
+    if (threadIdx.x == 0) loss[0] = scale * ((float)(a / (double)n1) + (float)(b / (double)n2));
+}
+
+__global__ __launch_bounds__(256) void adv_loss_bwd_kernel(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
+                                                           float label, float scale, const float* __restrict__ g,
+                                                           float* __restrict__ g1, float* __restrict__ g2) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const float gs = g[0] * scale;
+    if (e < n1) g1[e] = (sigmoidf_(d1[e]) - label) * gs / (float)n1;
+    if (e < n2) g2[e] = (sigmoidf_(d2[e]) - label) * gs / (float)n2;
+}
+
+extern "C" int uda_adv_loss_fwd(const float* d1, int n1, const float* d2, int n2, float label, float scale, float* loss, void* stream) {
+    UDA_REQUIRE(d1 && d2 && loss && n1 > 0 && n2 > 0, "uda_adv_loss_fwd: bad args");
+    hipLaunchKernelGGL(adv_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d1, n1, d2, n2, label, scale, loss);
+    UDA_LAUNCH_CHECK("adv_loss_fwd");
+    return 0;
+}
+
+extern "C" int uda_adv_loss_bwd(const float* d1, int n1, const float* d2, int n2, float label, float scale, const float* g, float* g1,
+                                float* g2, void* stream) {
+    UDA_REQUIRE(d1 && d2 && g && g1 && g2 && n1 > 0 && n2 > 0, "uda_adv_loss_bwd: bad args");
+    const int n = n1 > n2 ? n1 : n2;
+    hipLaunchKernelGGL(adv_loss_bwd_kernel, dim3(uda_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, d1, n1, d2, n2, label, scale, g, g1, g2);
+    UDA_LAUNCH_CHECK("adv_loss_bwd");
+    return 0;
+}

@@ -26,13 +26,15 @@ class PatchDiscriminatorEngine:
     def __init__(self, kernels):
         self.K = kernels
 
-    def forward(self, x, weights, need_grad):
-        """x: [N, C, H, W] (NCHW, as the reference feeds it).  Returns ([N, 1, Ho, Wo] logits, ctx)."""
+    def forward(self, x, weights, need_grad, pre_op=0):
+        """x: [N, C, H, W] (NCHW, as the reference feeds it).  ``pre_op`` 1 / 2: x holds generator LOGITS and the first layer
+        reads sigmoid(x) / the uncertainty map -sigmoid(x) log(sigmoid(x) + 1e-7) (Trainer_prototype_full.py:452-454) - applied
+        inside the space-to-depth pass, no full-resolution map is written.  Returns ([N, 1, Ho, Wo] logits, ctx)."""
         K = self.K
         N, Cc, H, W = x.shape
         src, nchw, Hs, Ws, vh, vw, slope = x, True, H, W, H, W, 1.0
         layers = []
-        for w in weights:
+        for li, w in enumerate(weights):
             O = w.shape[0]
             # z-space operands, built per forward (torch's fused optimizer steps do not bump a parameter's version,
             # so a cross-forward cache could go stale unnoticed)
@@ -40,19 +42,22 @@ class PatchDiscriminatorEngine:
             wd = K.relayout_s2d(w, True) if need_grad else None
             Hz, Wz = _zgrid(vh), _zgrid(vw)
             z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
-            K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
+            if li == 0 and pre_op:
+                K.adv_s2d_fwd(src, pre_op, z)
+            else:
+                K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
             y = torch.empty((N * Hz * Wz, round4(O)), dtype=torch.float32, device=x.device)[:, :O]
             K.conv(Act(z, N, Hz, Wz), wf, 2, 1, y, origin=0)
             layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd))
             src, nchw, Hs, Ws, Cc, slope = y, False, Hz, Wz, O, SLOPE
             vh, vw = vh // 2 + 1, vw // 2 + 1
         out = src.reshape(N, Hs, Ws, Cc)[:, :vh, :vw].permute(0, 3, 1, 2)
-        return out, ((layers, N, tuple(x.shape)) if need_grad else None)
+        return out, ((layers, N, tuple(x.shape), (x if pre_op else None), pre_op) if need_grad else None)
 
     def backward(self, ctx, gout, weights, need_x, need_w):
         """gout: gradient of the [N, 1, Ho, Wo] logits.  Returns (dx NCHW or None, [dw OIHW 4x4] or None)."""
         K = self.K
-        layers, N, xshape = ctx
+        layers, N, xshape, x_logits, pre_op = ctx
         z5, C5, Hs5, Ws5, vh5, vw5, Hz, Wz, _, _ = layers[-1]
         O = weights[-1].shape[0]
         vh, vw = vh5 // 2 + 1, vw5 // 2 + 1
@@ -76,7 +81,10 @@ class PatchDiscriminatorEngine:
             K.conv(Act(dy, N, Hz, Wz), wd, 2, 1, dz, origin=1)
             if nchw:
                 dx = torch.empty(xshape, dtype=torch.float32, device=z.device)
-                K.s2d_bwd(dz, None, 1.0, N, Hs, Ws, Cc, vh, vw, dx, True)
+                if pre_op:
+                    K.adv_s2d_bwd(dz, x_logits, pre_op, dx)
+                else:
+                    K.s2d_bwd(dz, None, 1.0, N, Hs, Ws, Cc, vh, vw, dx, True)
             else:
                 dyn = torch.empty((N * Hs * Ws, round4(Cc)), dtype=torch.float32, device=z.device)[:, :Cc]
                 K.s2d_bwd(dz, z, SLOPE, N, Hs, Ws, Cc, vh, vw, dyn, False)

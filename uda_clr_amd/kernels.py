@@ -97,6 +97,12 @@ SYMBOLS = {
     "uda_feat_dot4": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "uda_feat_rank4": (_I, [_P, _P, _L, _I, _P, _L, _I, _P]),
     "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
+    "uda_proto_align_fwd": (_I, [_P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P]),
+    "uda_proto_align_bwd": (_I, [_P, _P, _P, _F, _F, _I, _P, _P, _P]),
+    "uda_adv_loss_fwd": (_I, [_P, _I, _P, _I, _F, _F, _P, _P]),
+    "uda_adv_loss_bwd": (_I, [_P, _I, _P, _I, _F, _F, _P, _P, _P, _P]),
+    "uda_adv_s2d_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
+    "uda_adv_s2d_bwd": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "uda_upconv_fused_stats": (_I, [_I, _I, _I, _I, _I, _I]),
     "uda_upconv_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P, _P]),
     "uda_upconv_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
@@ -387,6 +393,24 @@ class HipKernels:
         self._ck(self.lib.uda_s2d_bwd(gp, _ptr(z_sign), ldz, Hz, Wz, float(slope), N, Hs, Ws, Cc, vh, vw, dp, ldd, int(nchw),
                                       self._stream()))
 
+    def adv_s2d_fwd(self, logits, pre_op, z):
+        """z = s2d(pre(logits)), logits NCHW [N,C,H,W]; pre_op 1 = sigmoid, 2 = -sigmoid * log(sigmoid + 1e-7)."""
+        self._dev(logits)
+        N, Cc, H, W = logits.shape
+        Hz, Wz = (H + 5) // 2, (W + 5) // 2
+        assert logits.is_contiguous() and logits.dtype == torch.float32 and z.shape == (N * Hz * Wz, 4 * Cc)
+        zp, ldz = _mat(z, "z")
+        self._ck(self.lib.uda_adv_s2d_fwd(logits.data_ptr(), N, Cc, H, W, int(pre_op), zp, ldz, Hz, Wz, self._stream()))
+
+    def adv_s2d_bwd(self, dz, logits, pre_op, d_logits):
+        N, Cc, H, W = logits.shape
+        Hz, Wz = (H + 5) // 2, (W + 5) // 2
+        assert dz.shape == (N * Hz * Wz, 4 * Cc) and logits.is_contiguous() and d_logits.is_contiguous()
+        assert tuple(d_logits.shape) == tuple(logits.shape)
+        gp, ldz = _mat(dz, "dz")
+        self._ck(self.lib.uda_adv_s2d_bwd(gp, ldz, Hz, Wz, logits.data_ptr(), N, Cc, H, W, int(pre_op), d_logits.data_ptr(),
+                                          self._stream()))
+
     # ------------------------------------------------------------------ batch norm
     def bn_finalize(self, stats, count, gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean, invstd):
         Cc = gamma.numel()
@@ -636,6 +660,42 @@ class HipKernels:
         self._ck(self.lib.uda_proto_bwd(f, ldf, P, Cc, wts.data_ptr(), sums.data_ptr(), dC.data_ptr(), coef.data_ptr(),
                                         dptr, ldd, int(accumulate), _ptr(d_w), self._stream()))
         return d_w
+
+    def proto_align_fwd(self, cur_src, cur_tgt, prev_src, prev_tgt, decay):
+        """-> (new_src [4,C], new_tgt [4,C], losses float[2] = (intra, inter)); prev_* None on first use."""
+        self._dev(cur_src)
+        Cc = cur_src.shape[1]
+        for t in (cur_src, cur_tgt, prev_src, prev_tgt):
+            assert t is None or (t.is_contiguous() and tuple(t.shape) == (4, Cc) and t.dtype == torch.float32)
+        new_src, new_tgt = torch.empty_like(cur_src), torch.empty_like(cur_tgt)
+        losses = torch.empty(2, dtype=torch.float32, device=cur_src.device)
+        self._ck(self.lib.uda_proto_align_fwd(cur_src.data_ptr(), cur_tgt.data_ptr(), _ptr(prev_src), _ptr(prev_tgt),
+                                              float(1 - decay), float(decay), Cc, new_src.data_ptr(), new_tgt.data_ptr(),
+                                              losses.data_ptr(), self._stream()))
+        return new_src, new_tgt, losses
+
+    def proto_align_bwd(self, new_src, new_tgt, g, w_src, w_tgt):
+        Cc = new_src.shape[1]
+        assert g.numel() == 1 and g.dtype == torch.float32 and new_src.is_contiguous() and new_tgt.is_contiguous()
+        d_src, d_tgt = torch.empty_like(new_src), torch.empty_like(new_tgt)
+        self._ck(self.lib.uda_proto_align_bwd(new_src.data_ptr(), new_tgt.data_ptr(), g.data_ptr(), float(w_src), float(w_tgt), Cc,
+                                              d_src.data_ptr(), d_tgt.data_ptr(), self._stream()))
+        return d_src, d_tgt
+
+    def adv_loss_fwd(self, d1, d2, label, scale):
+        self._dev(d1)
+        assert d1.is_contiguous() and d2.is_contiguous() and d1.dtype == d2.dtype == torch.float32
+        loss = torch.empty(1, dtype=torch.float32, device=d1.device)
+        self._ck(self.lib.uda_adv_loss_fwd(d1.data_ptr(), d1.numel(), d2.data_ptr(), d2.numel(), float(label), float(scale),
+                                           loss.data_ptr(), self._stream()))
+        return loss
+
+    def adv_loss_bwd(self, d1, d2, label, scale, g):
+        assert g.numel() == 1 and g.dtype == torch.float32
+        g1, g2 = torch.empty_like(d1), torch.empty_like(d2)
+        self._ck(self.lib.uda_adv_loss_bwd(d1.data_ptr(), d1.numel(), d2.data_ptr(), d2.numel(), float(label), float(scale),
+                                           g.data_ptr(), g1.data_ptr(), g2.data_ptr(), self._stream()))
+        return g1, g2
 
     def feat_dot4(self, feat, coef):
         """[P,4]: feat @ coef[:, :C].T + coef[:, C]"""

@@ -14,9 +14,9 @@ from ..gan_engine import PatchDiscriminatorEngine
 
 class _DiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, x, need, *weights):
+    def forward(ctx, module, x, need, pre_op, *weights):
         engine = module._engine_for(x)
-        out, ectx = engine.forward(x.contiguous().float(), weights, need)
+        out, ectx = engine.forward(x.contiguous().float(), weights, need, pre_op)
         ctx.engine, ctx.ectx, ctx.module, ctx.weights = engine, ectx, module, weights
         return out
 
@@ -26,13 +26,13 @@ class _DiscFn(torch.autograd.Function):
             raise RuntimeError("discriminator forward ran without gradient bookkeeping")
         mode = ctx.module.grad_mode
         need_x = ctx.needs_input_grad[1] and mode in ("auto", "input")
-        need_w = any(ctx.needs_input_grad[3:]) and mode in ("auto", "weights")
+        need_w = any(ctx.needs_input_grad[4:]) and mode in ("auto", "weights")
         dx, dws = ctx.engine.backward(ctx.ectx, gout, ctx.weights, need_x, need_w)
         if mode != "input":
             ctx.ectx = None
         if dws is None:
             dws = [None] * len(ctx.weights)
-        return (None, dx, None) + tuple(dws)
+        return (None, dx, None, None) + tuple(dws)
 
 
 class _PatchDiscriminator(nn.Module):
@@ -64,12 +64,19 @@ class _PatchDiscriminator(nn.Module):
             self._engine = PatchDiscriminatorEngine(HipKernels())
         return self._engine
 
-    def forward(self, x):
+    fused_pre = True      # forward(x, pre=...) accepts generator logits (see below); stock modules have no such attribute
+    _PRE = {None: 0, "sigmoid": 1, "entropy": 2}
+
+    def forward(self, x, pre=None):
+        """``pre`` (extension of the reference's ``forward(x)``): "sigmoid" / "entropy" = x holds generator logits and the
+        discriminator reads sigmoid(x) / -sigmoid(x) * log(sigmoid(x) + 1e-7) (the two maps Trainer_prototype_full.py:452-454
+        builds with elementwise torch ops); the map is formed inside the first layer's space-to-depth pass and its derivative
+        inside the adjoint pass."""
         if x.dim() != 4 or x.shape[1] != self.conv1.weight.shape[1]:
             raise ValueError("expected an [N, %d, H, W] batch" % self.conv1.weight.shape[1])
         weights = [getattr(self, "conv%d" % i).weight for i in range(1, 6)]
         need = torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights))
-        return _DiscFn.apply(self, x, need, *weights)
+        return _DiscFn.apply(self, x, need, self._PRE[pre], *weights)
 
 
 class UncertaintyDiscriminator(_PatchDiscriminator):

@@ -93,9 +93,76 @@ class _ProtoFn(torch.autograd.Function):
         return d_feat, None, d_pred
 
 
+class Centroids(tuple):
+    """(cup_obj, disc_obj, cup_bck, disc_bck) as [1,C,1,1] views, like the reference's four return values, plus ``.matrix``,
+    the [4, C] tensor they are rows of (what the fused alignment kernel takes)."""
+    matrix = None
+    centroids = None       # gen_prototype_retrify's 7-tuple: its first four entries as a Centroids of their own
+
+
 def _split(cent):
     C = cent.shape[1]
-    return tuple(cent[k].reshape(1, C, 1, 1) for k in range(4))
+    out = Centroids(cent[k].reshape(1, C, 1, 1) for k in range(4))
+    out.matrix = cent
+    return out
+
+
+def _matrix(cents):
+    m = getattr(cents, "matrix", None)
+    return m if m is not None else torch.cat([t.reshape(1, -1) for t in cents], 0)
+
+
+class _AlignFn(torch.autograd.Function):
+    """EMA of both domains' centroids + intra / inter losses in one launch (uda_proto_align_fwd); backward: one launch for both
+    current-centroid gradients (the EMA keeps gradient only through the current term, quirk Q4)."""
+
+    @staticmethod
+    def forward(ctx, cur_src, cur_tgt, prev_src, prev_tgt, decay):
+        K = kernels()
+        new_src, new_tgt, losses = K.proto_align_fwd(cur_src.contiguous().float(), cur_tgt.contiguous().float(),
+                                                     prev_src, prev_tgt, decay)
+        ctx.save_for_backward(new_src, new_tgt)
+        ctx.w = (1.0 if prev_src is None else decay, 1.0 if prev_tgt is None else decay)
+        ctx.mark_non_differentiable(new_src, new_tgt)
+        return losses[0], losses[1], new_src, new_tgt
+
+    @staticmethod
+    def backward(ctx, g_intra, g_inter, _a, _b):
+        new_src, new_tgt = ctx.saved_tensors
+        if g_inter is not None and bool((g_inter != 0).any()):
+            raise NotImplementedError("inter_loss is logged only (Trainer_prototype_full.py:443-449, :465); no gradient is built for it")
+        d_src, d_tgt = kernels().proto_align_bwd(new_src, new_tgt, g_intra.reshape(1).contiguous().float(), ctx.w[0], ctx.w[1])
+        return d_src, d_tgt, None, None, None
+
+
+def proto_align(cur_src, cur_tgt, prev_src, prev_tgt, decay):
+    """Trainer_prototype_full.py:335-355, 378-398, 428-444 fused: returns (intra_loss, inter_loss, src, tgt) where src / tgt
+    are the DETACHED EMA centroids to store for the next iteration (``Centroids``); ``prev_*`` is that stored state or None."""
+    ps = None if prev_src is None else _matrix(prev_src).detach().contiguous()
+    pt = None if prev_tgt is None else _matrix(prev_tgt).detach().contiguous()
+    intra, inter, new_src, new_tgt = _AlignFn.apply(_matrix(cur_src), _matrix(cur_tgt), ps, pt, float(decay))
+    return intra, inter, _split(new_src), _split(new_tgt)
+
+
+class _AdvLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d1, d2, label, scale):
+        d1, d2 = d1.contiguous().float(), d2.contiguous().float()
+        ctx.save_for_backward(d1, d2)
+        ctx.args = (label, scale)
+        return kernels().adv_loss_fwd(d1, d2, label, scale)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2 = ctx.saved_tensors
+        g1, g2 = kernels().adv_loss_bwd(d1, d2, ctx.args[0], ctx.args[1], g.reshape(1).contiguous().float())
+        return g1, g2, None, None
+
+
+def adv_loss(d_out1, d_out2, label, scale=1.0):
+    """scale * (BCEWithLogits(d_out1, label) + BCEWithLogits(d_out2, label)) on the two patch-discriminator outputs
+    (Trainer_prototype_full.py:456-458, 479-513): one launch forward, one for both gradients."""
+    return _AdvLossFn.apply(d_out1, d_out2, float(label), float(scale))
 
 
 def gen_prototype(pred, feature):
@@ -123,7 +190,9 @@ def gen_prototype_retrify(oT_before, xt_feature, preds, features, T, stride):
     std_map, mean_map = K.mc_stats(preds.detach().contiguous().float(), T)
     wts, m0, m1 = K.proto_weights(2, B, h, w, logits=rows_view(oT_before.detach()), std_map=std_map, mean_map=mean_map)
     cents = _split(_ProtoFn.apply(xt_feature, wts, None))
-    return cents + (std_map, m0.reshape(B, 1, h, w), m1.reshape(B, 1, h, w))
+    out = Centroids(tuple(cents) + (std_map, m0.reshape(B, 1, h, w), m1.reshape(B, 1, h, w)))     # the reference's 7 return values
+    out.matrix, out.centroids = None, cents
+    return out
 
 
 class _DiscriminativeFn(torch.autograd.Function):

@@ -14,6 +14,7 @@ import timeit
 
 import torch
 
+from ..optim import take_over
 from ..parallel import FlatGradAllReduce
 from ._common import (HipOps, TrainerBase, decorrelate_dropout, get_lr, nan_guard, prefer_fused, progress, shard_loader,
                       sync_replicas, trange)
@@ -29,7 +30,7 @@ class Trainer(TrainerBase):
         self.cuda = cuda
         self.warmup_epoch = warmup_epoch
         self.model_gen = model_gen
-        self.optim_gen = prefer_fused(optimizer_gen)
+        self.optim_gen = prefer_fused(take_over(optimizer_gen))      # Adam on the flat multi-tensor kernel (uda_clr_amd.optim)
         self.lr_gen = lr_gen
         self.lr_decrease_rate = lr_decrease_rate
         self.batch_size = batch_size

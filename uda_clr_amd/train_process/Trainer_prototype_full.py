@@ -10,8 +10,9 @@ One iteration (Trainer_prototype_full.py:261-517):
        source prototypes from the (nearest-resized) labels, EMA             [one fused reduction]
        4 no-grad stochastic passes on the doubled target batch (T = 8)
        retrified target prototypes (or soft ones), EMA                      [fused HIP kernels]
-       intra = sum_k MSE(src_k, tgt_k);  inter logged only
-  4. adversarial term through the two patch discriminators (stock PyTorch-ROCm)
+       EMA + intra = sum_k MSE(src_k, tgt_k) + inter (logged only)            [one fused kernel, one for its gradients]
+  4. adversarial term through the two patch discriminators (native kernels; the sigmoid / uncertainty maps are formed
+     inside their first layer, the two BCE-with-logits terms are one kernel)
   5. generator backward + Adam; discriminator steps on detached outputs (SGD)
 
 Deviations from the shipped file, all documented in DESIGN.md:
@@ -30,6 +31,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ..optim import take_over
 from ..parallel import FlatGradAllReduce
 from ._common import (HipOps, TrainerBase, decorrelate_dropout, get_lr, nan_guard, prefer_fused, progress, shard_loader,
                       sync_replicas, trange)
@@ -68,7 +70,7 @@ class Trainer(TrainerBase):
         self.aug_weight, self.src_reg_weight = aug_weight, src_reg_weight
         self.model_dis2 = model_uncertainty_dis
         self.model_dis = model_dis
-        self.optim_gen = prefer_fused(optimizer_gen)
+        self.optim_gen = prefer_fused(take_over(optimizer_gen))      # Adam on the flat multi-tensor kernel (uda_clr_amd.optim)
         self.optim_dis = prefer_fused(optimizer_dis)
         self.optim_dis2 = prefer_fused(optimizer_uncertainty_dis)
         self.lr_gen = lr_gen
@@ -139,6 +141,21 @@ class Trainer(TrainerBase):
     @staticmethod
     def _adv(d_out, label):
         return F.binary_cross_entropy_with_logits(d_out, torch.full_like(d_out, float(label)))
+
+    def _disc(self, d, logits, pre):
+        """The discriminator on sigmoid(logits) (boundary branch) or on the uncertainty map of the logits (:452-454).  The native
+        discriminators form the map inside their first layer (networks/GAN.py ``forward(x, pre=...)``); any other module gets
+        the reference's elementwise expressions."""
+        if getattr(d, "fused_pre", False):
+            return d(logits, pre=pre)
+        return d(torch.sigmoid(logits) if pre == "sigmoid" else self._uncertainty(logits))
+
+    def _adv_pair(self, d1, d2, label, scale):
+        """scale * (BCEWithLogits(d1, label) + BCEWithLogits(d2, label)) (:456-458, :479-513)"""
+        if hasattr(self.ops, "adv_loss"):
+            return self.ops.adv_loss(d1, d2, label, scale)
+        s = self._adv(d1, label) + self._adv(d2, label)
+        return s if scale == 1.0 else scale * s
 
     def _prototypes_on(self):
         return self.use_pid and self.epoch > self.warmup_epoch
@@ -217,7 +234,7 @@ class Trainer(TrainerBase):
         intra_loss = None
         if self._prototypes_on():                                                            # :328-449
             cur_src = ops.gen_prototype_from_labels(target_map, xs_feature)                  # :330-334
-            src, self.src_centroids = self._ema(self.src_centroids, cur_src)
+            prev_src = self.src_centroids
             T = 8
             volume_batch_r = imageT.repeat(2, 1, 1, 1)
             stride = volume_batch_r.shape[0] // 2
@@ -232,21 +249,28 @@ class Trainer(TrainerBase):
                         preds_trg[2 * stride * i:2 * stride * (i + 1)] = gen(volume_batch_r)[0]
             if self.retrify_pesudo:
                 res = ops.gen_prototype_retrify(oT_before, xt_feature, preds_trg, None, T, stride)
-                cur_tgt = res[:4]
+                cur_tgt = getattr(res, "centroids", None) or res[:4]
                 self.target_std_map, self.mask_0, self.mask_1 = res[4:]
             else:
                 cur_tgt = ops.gen_prototype(torch.sigmoid(oT_before), xt_feature)            # :375-377
-            tgt, self.tgt_centroids = self._ema(self.tgt_centroids, cur_tgt)
-            intra_loss = sum(mseloss(s, t) for s, t in zip(src, tgt))                        # :428-441
-            inter_loss = mseloss(src[1], src[3]) + mseloss(src[0], src[2])                   # :443-444 (logged only)
+            if hasattr(ops, "proto_align"):
+                # :335-355, :378-398, :428-444 as one launch (+ one for both gradients): EMA of the eight centroids with the
+                # stored (detached) state, intra / inter; the returned centroids are the detached EMA state of the next step
+                intra_loss, inter_loss, self.src_centroids, self.tgt_centroids = ops.proto_align(
+                    cur_src, cur_tgt, prev_src, self.tgt_centroids, self.global_pro_weight)
+                src = self.src_centroids
+            else:
+                src, self.src_centroids = self._ema(prev_src, cur_src)
+                tgt, self.tgt_centroids = self._ema(self.tgt_centroids, cur_tgt)
+                intra_loss = sum(mseloss(s, t) for s, t in zip(src, tgt))                    # :428-441
+                inter_loss = mseloss(src[1], src[3]) + mseloss(src[0], src[2])               # :443-444 (logged only)
             self.First_src = self.First = False
             if self.src_reg:                                                                 # Appendix B (unpinned)
                 pred_oS = F.interpolate(target_map, size=xs_feature.shape[2:], mode='nearest')
                 self.loss_src_reg = ops.discriminative_loss(xs_feature, src, pred_oS)
-        uncertainty_mapT = self._uncertainty(oT)                                             # :452-458
-        D_out2 = dis(torch.sigmoid(boundaryT))
-        D_out1 = dis2(uncertainty_mapT)
-        loss_adv_diff = 0.01 * (self._adv(D_out1, 1) + self._adv(D_out2, 1))
+        D_out2 = self._disc(dis, boundaryT, "sigmoid")                                       # :452-454
+        D_out1 = self._disc(dis2, oT, "entropy")
+        loss_adv_diff = self._adv_pair(D_out1, D_out2, 1, 0.01)                              # :456-458
         scalars.append(loss_adv_diff.detach())
         loss_all = loss_seg + loss_adv_diff
         if intra_loss is not None:
@@ -271,9 +295,9 @@ class Trainer(TrainerBase):
         # ---- discriminators on detached generator outputs (:471-517)
         self._set_requires_grad((gen,), False)
         oS, boundaryS = oS.detach(), boundaryS.detach()
-        loss_D_same = self._adv(dis2(self._uncertainty(oS)), 1) + self._adv(dis(torch.sigmoid(boundaryS)), 1)
+        loss_D_same = self._adv_pair(self._disc(dis2, oS, "entropy"), self._disc(dis, boundaryS, "sigmoid"), 1, 1.0)
         loss_D_same.backward()
-        loss_D_diff = self._adv(D_out1, 0) + self._adv(D_out2, 0)
+        loss_D_diff = self._adv_pair(D_out1, D_out2, 0, 1.0)
         self._grad_mode((dis, dis2), "weights")
         loss_D_diff.backward(inputs=dis_params)
         self._grad_mode((dis, dis2), "auto")

@@ -77,6 +77,8 @@ class HipOps:
         self.elastic_deform = ops.elastic_deform
         self.photometric_u8 = ops.photometric_u8
         self.consistency_loss = ops.consistency_loss
+        self.proto_align = ops.proto_align
+        self.adv_loss = ops.adv_loss
         self.dice_coeff_2label = metrics.dice_coeff_2label
         self.pixel_acc = metrics.pixel_acc
 

@@ -11,8 +11,12 @@ on): one Trainer_prototype_full iteration with B=16 source + 16 target images pe
 forward -> BCE+MSE seg loss -> backward -> Adam (Trainer_baseline.py:198-243).  Data parallel: one process per GPU, per-rank batch fixed (weak
 scaling), one flat RCCL all-reduce of the generator gradients per step; BN statistics stay per rank
 as in the reference.  Rank 0 prints ONE JSON line with the metric, the roofline of the dominant
-kernel (FP32-MFMA implicit-GEMM 3x3 convolutions, timed live with HIP events on the launch stream)
-and the CPU baseline (the oracle restatement on the host cores, bounded sample).
+kernel (the wide-tile multi-tap implicit GEMM of the 3x3 / 2x2 convolutions, timed live with HIP events on the
+launch stream) and the CPU baseline (the oracle restatement on the host cores, bounded sample).
+
+``--mfma`` selects the matrix instructions of that kernel: ``bf16x3`` (default) = fp32 emulated on the bf16 pipe by exact
+3-way operand splitting (fp32-level results), ``f32`` = v_mfma_f32_32x32x2_f32.  The line of the default run
+also carries a short measurement of the other mode (``other_mfma``), outside the timed region.
 """
 import argparse
 import json
@@ -26,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 (v_mfma_f32_32x32x16_bf16)
+# bf16x3: six bf16 MFMA products per fp32 product, so the fp32-EQUIVALENT ceiling of that kernel is the bf16 peak / 6
+PEAK_BF16X3_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def synth_batch(B, S, seed, device):
@@ -48,64 +55,102 @@ def synth_batch(B, S, seed, device):
 
 
 class ConvTimer:
-    """HIP-event timing of the dominant kernel's launches inside the timed region: wraps HipKernels.conv and
-    records an event pair around every launch of the wide-tile multi-tap implicit GEMM (one kernel symbol,
-    igemm_conv_ws_kernel<3,...>: forward and input-gradient of the decoder / ASPP 3x3 convolutions and of the
-    discriminators' 4x4 stride-2 convolutions in their 2x2 space-to-depth form)."""
+    """HIP-event timing of the dominant kernel's launches inside the timed region (events on torch's current stream, the stream
+    the kernels are launched on).  The dominant kernel is the wide-tile multi-tap implicit GEMM: forward and input-gradient of
+    the decoder / ASPP 3x3 convolutions and of the discriminators' 4x4 stride-2 convolutions in their 2x2 space-to-depth form -
+    igemm_conv_x3_kernel<3,...> in bf16x3 mode (HipKernels._conv_x3 is that launch alone; the operand-packing passes are separate
+    kernels and are NOT inside the bracket), igemm_conv_ws_kernel<3,...> in f32 mode."""
 
     def __init__(self, kernel_class):
         """Patches the binding CLASS so that every HipKernels instance (generator engine, discriminator engines) is timed."""
-        self.orig = kernel_class.conv
+        self.kernel_class = kernel_class
+        self.orig_conv, self.orig_x3 = kernel_class.conv, kernel_class._conv_x3
         self.events, self.flops, self.bytes, self.enabled = [], [], [], False
+        self.pending = None
         timer = self
 
-        def conv(inst, *a, **kw):
-            return timer._conv(inst, *a, **kw)
-        kernel_class.conv = conv
+        def conv(inst, src, w, ksize, dil, out, *a, **kw):
+            hot = timer.enabled and ksize >= 2 and out.shape[1] > 96 and ksize * ksize * src.C > 192   # the wide-tile multi-tap kernel
+            if not hot:
+                return timer.orig_conv(inst, src, w, ksize, dil, out, *a, **kw)
+            taps = ksize * ksize
+            work = (2.0 * src.P * out.shape[1] * taps * src.C,                                       # algorithmic: 2*P*Cout*taps*Cin
+                    4.0 * (src.P * (src.C + out.shape[1]) + out.shape[1] * taps * src.C))            # in + out + weights once, fp32
+            if inst.mfma == inst.MFMA_F32:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = timer.orig_conv(inst, src, w, ksize, dil, out, *a, **kw)
+                e1.record()
+                timer._add(e0, e1, work)
+                return r
+            timer.pending = work                    # bf16x3: the bracket goes around the GEMM launch inside (after the packing passes)
+            try:
+                return timer.orig_conv(inst, src, w, ksize, dil, out, *a, **kw)
+            finally:
+                timer.pending = None
 
-    def _conv(self, inst, src, w, ksize, dil, out, bias=None, addend=None, stats=None, **kw):
-        hot = self.enabled and ksize >= 2 and out.shape[1] > 96 and ksize * ksize * src.C > 192      # the wide-tile multi-tap kernel
-        if hot:
+        def conv_x3(inst, a):
+            if timer.pending is None:
+                return timer.orig_x3(inst, a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.orig(inst, src, w, ksize, dil, out, bias, addend, stats, **kw)
-        if hot:
+            r = timer.orig_x3(inst, a)
             e1.record()
-            self.events.append((e0, e1))
-            taps = ksize * ksize
-            self.flops.append(2.0 * src.P * out.shape[1] * taps * src.C)      # algorithmic: 2*P*Cout*taps*Cin
-            self.bytes.append(4.0 * (src.P * (src.C + out.shape[1]) + out.shape[1] * taps * src.C))   # in + out + weights, once each
+            timer._add(e0, e1, timer.pending)
+            return r
+        kernel_class.conv, kernel_class._conv_x3 = conv, conv_x3
 
-    def summary(self, traffic=None):
-        """traffic: measured HBM bytes per launch (rocprofv3 PMC passes, profiles/*_traffic.json) or None."""
+    def _add(self, e0, e1, work):
+        self.events.append((e0, e1))
+        self.flops.append(work[0])
+        self.bytes.append(work[1])
+
+    def restore(self):
+        self.kernel_class.conv, self.kernel_class._conv_x3 = self.orig_conv, self.orig_x3
+
+    def summary(self, mode, traffic=None):
+        """traffic: (GB per launch, source file) measured by PMC passes of this configuration, or None."""
         if not self.events:
             return None
         ms = [a.elapsed_time(b) for a, b in self.events]
         tf = sum(self.flops) / (sum(ms) * 1e-3) / 1e12
-        return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "algorithmic_gb_per_launch": round(sum(self.bytes) / len(ms) / 1e9, 4),
-                "kernel": "igemm_conv_ws_kernel<3,*> (multi-tap implicit GEMM: forward + input-gradient of the decoder / ASPP 3x3 "
-                          "convs and of the discriminators' 4x4 s2 convs as 2x2 space-to-depth convs)",
-                "launches": len(ms), "avg_launch_ms": round(sum(ms) / len(ms), 4),
-                "algorithmic_gflop_per_launch": round(sum(self.flops) / len(ms) / 1e9, 2)}
+        x3 = mode == "bf16x3"
+        peak = PEAK_BF16X3_EQUIV_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+        out = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1),
+               "unit": "TFLOP/s" + (" (fp32-equivalent: algorithmic fp32 FLOPs; the kernel issues 6 bf16 MFMA FLOPs per algorithmic "
+                                    "FLOP, peak = dense bf16 2500 / 6)" if x3 else ""),
+               "frac": round(tf / peak, 4), "traffic": None if traffic is None else traffic[0],
+               "traffic_source": None if traffic is None else traffic[1],
+               "algorithmic_gb_per_launch": round(sum(self.bytes) / len(ms) / 1e9, 4),
+               "kernel": ("igemm_conv_x3_kernel<3,*> (bf16x3" if x3 else "igemm_conv_ws_kernel<3,*> (fp32 MFMA") +
+                         " multi-tap implicit GEMM: forward + input-gradient of the decoder / ASPP 3x3 convs and of the "
+                         "discriminators' 4x4 s2 convs as 2x2 space-to-depth convs)",
+               "launches": len(ms), "avg_launch_ms": round(sum(ms) / len(ms), 4),
+               "algorithmic_gflop_per_launch": round(sum(self.flops) / len(ms) / 1e9, 2)}
+        if x3:
+            out["executed_bf16_tflops"] = round(6.0 * tf, 1)
+            out["frac_of_f32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TFLOPS, 3)
+        return out
 
 
-def measured_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS configuration
-    (profiles/r01_igemm_conv_ws_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, see profiles/pmc_traffic.py), in GB;
-    None for any other configuration (counters cannot be collected from inside the timed run)."""
-    if (args.workload, args.backbone, args.batch, args.size, args.use_tn) != ("prototype_full", "mobilenet", 16, 512, False):
+def measured_traffic(args, mode):
+    """(GB of HBM traffic per launch of the dominant kernel, file it comes from) out of the committed PMC passes of THIS
+    configuration and matrix mode (profiles/r02_*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per launch, profiles/pmc_traffic.py);
+    None for any other configuration.  It is NOT measured by this run - counters cannot be collected inside the timed region."""
+    if (args.workload, args.backbone, args.size, args.use_tn) != ("prototype_full", "mobilenet", 512, False):
         return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_conv_ws_traffic.json")
+    name = "r02_igemm_conv_%s_b%d_traffic.json" % ("x3" if mode == "bf16x3" else "ws", args.batch)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        return round(json.load(f)["hbm_bytes_per_launch"] / 1e9, 4)
+        return round(json.load(f)["hbm_bytes_per_launch"] / 1e9, 4), "profiles/" + name
 
 
-def cpu_baseline(workload, B, S, backbone="mobilenet"):
-    """The oracle restatement of the same step on the host cores (bounded sample)."""
+def cpu_baseline(workload, B, S, backbone="mobilenet", budget_s=25.0):
+    """The oracle restatement of the same step on the host cores: a bounded sample (about ``budget_s`` seconds of CPU work).
+    Thread count: every count in {8, 16, 32, all} gets one probe step; the fastest one then runs >= 3 timed steps (all cores is
+    NOT the fastest for this network: oversubscribed small layers; round 1 reported 0.149 img/s on 128 threads against 0.295 on 8)."""
     from oracle import deeplab_ref, step_ref
     from oracle.gan_ref import BoundaryDiscriminator, UncertaintyDiscriminator
     from uda_clr_amd.networks.deeplabv3 import DeepLab
@@ -117,24 +162,40 @@ def cpu_baseline(workload, B, S, backbone="mobilenet"):
     if workload == "source_only":
         opt = torch.optim.Adam(om.parameters(), lr=1e-3, betas=(0.9, 0.99))
         run = lambda: step_ref.baseline_step(om, opt, img, tmap, tbd)
-        n_img, steps = B, 5
+        n_img = B
     else:
         d1, d2 = BoundaryDiscriminator().train(), UncertaintyDiscriminator().train()
         og, od, od2 = step_ref.make_optimizers(om, d1, d2)
         stepper = step_ref.PrototypeFullStep(om, d1, d2, og, od, od2)
         run = lambda: stepper(img, tmap, tbd, imgT)
-        n_img, steps = 2 * B, 1
-    run()            # warm-up
+        n_img = 2 * B
+    ncpu = os.cpu_count() or 8
+    keep = torch.get_num_threads()
+    probes, t_all = {}, time.perf_counter()
+    for nt in sorted({min(n, ncpu) for n in (8, 16, 32, ncpu)}):
+        torch.set_num_threads(nt)
+        if not probes:
+            run()                                   # warm-up (allocator, first-touch)
+        t0 = time.perf_counter()
+        run()
+        probes[nt] = time.perf_counter() - t0
+        if time.perf_counter() - t_all > 0.6 * budget_s:
+            break
+    best = min(probes, key=probes.get)
+    torch.set_num_threads(best)
     ts = []
-    for _ in range(steps):
+    while len(ts) < 3 or (time.perf_counter() - t_all < budget_s and len(ts) < 10):
         t0 = time.perf_counter()
         run()
         ts.append(time.perf_counter() - t0)
+    torch.set_num_threads(keep)
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"value": round(n_img / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d step(s) (median) of the %s step at B=%d%s, %dx%d, oracle restatement on the host cores"
-                      % (steps, workload, B, "" if workload == "source_only" else "+%d" % B, S, S)}
+    return {"value": round(n_img / med, 3), "unit": "images/sec", "cores": best, "kind": "port",
+            "sample": "%d timed step(s) (median) of the %s step at B=%d%s, %dx%d, oracle restatement on %d of the %d host cores; "
+                      "probe seconds per step by thread count: %s"
+                      % (len(ts), workload, B, "" if workload == "source_only" else "+%d" % B, S, S, best, ncpu,
+                         {k: round(v, 2) for k, v in probes.items()})}
 
 
 def main():
@@ -150,7 +211,13 @@ def main():
     ap.add_argument("--use-tn", action="store_true",
                     help="the --use_TN model of train_use_fix_initial.py:98-100,180-181 (TransNorm layers; not a BASELINE.json config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mfma", choices=("bf16x3", "f32"), default=None,
+                    help="matrix instructions of the wide conv tiles (default: UDA_CLR_MFMA or bf16x3)")
+    ap.add_argument("--no-other-mfma", action="store_true", help="skip the short measurement of the other matrix mode")
     args = ap.parse_args()
+    if args.mfma:
+        os.environ["UDA_CLR_MFMA"] = args.mfma
+    mode = os.environ.get("UDA_CLR_MFMA", "bf16x3").lower()
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,6 +310,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = [round(float(v), 5) for v in (last if isinstance(last, list) else [last.item()])]
+    # the other matrix mode, outside the timed region: same step, 2 warm-up + 5 timed steps (all ranks take part)
+    other = None
+    timer.restore()
+    if not args.no_other_mfma:
+        om = "f32" if mode == "bf16x3" else "bf16x3"
+        insts = [o for o in __import__("gc").get_objects() if isinstance(o, HipKernels)]
+        for o in insts:
+            o.mfma = o.MFMA_F32 if om == "f32" else o.MFMA_BF16X3
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        sync()
+        dto = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([dto], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dto = t.item()
+        other = {"mfma": om, "value": round(per_step * world * 5 / dto, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dto / 5, 3),
+                 "steps": 5}
     if rank == 0:
         images = per_step * world * args.steps
         desc = {"source_only": "source_only: Trainer_baseline step (fwd, BCE+MSE, bwd, Adam), DeepLabV3+/MobileNetV2 %dx%d "
@@ -263,8 +352,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc % fmt, "global_batch": per_step * world, "parallelism": "dp%d" % world,
-                       "last_step_losses": losses},
-            "roofline": timer.summary(measured_traffic(args)),
+                       "last_step_losses": losses,
+                       "mfma": ("bf16x3: inputs, outputs, accumulators and statistics fp32/fp64; the wide conv tiles multiply on the "
+                                "bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces (six piece products, "
+                                "fp32 accumulate) - fp32-level results, error against float64 measured equal to the fp32-MFMA "
+                                "kernel's (DESIGN.md 3d, tests/bench_x3.py); the exact fp32-MFMA path is `--mfma f32`, measured "
+                                "in `other_mfma`") if mode == "bf16x3" else "f32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"},
+            "roofline": timer.summary(mode, measured_traffic(args, mode)),
         }
         # step-level figures of SURVEY.md 8(d): algorithmic GFLOP / GB per counted image (reference algorithm,
         # i.e. the 4 MC passes counted as full forwards although the fast path recomputes only their stochastic tail)
@@ -288,12 +382,18 @@ def main():
                 tfe = line["value"] / world * executed / 1e3
                 line["step_roofline"].update(executed_gflop_per_image=executed, executed_tflops_per_gpu=round(tfe, 2),
                                              executed_mfma_frac=round(tfe / 157.3, 4))
-            if (args.backbone, args.workload) == ("mobilenet", "source_only"):
-                gbs = line["value"] / world * 1.39
-                line["step_roofline"].update(algorithmic_gb_per_image=1.39, achieved_gb_s_per_gpu=round(gbs, 1),
+            # SURVEY.md 8d reporting rule: the HBM fraction beside the FLOP-based one.  Algorithmic bytes per counted image:
+            # 1.39 GB per training pass of the generator (source_only); prototype_full = (2 generator training passes * 1.39 +
+            # 8 MC image-passes * 0.46 GB forward + two discriminators ~0.6 GB per image pair: ten passes over their ~32 MB of layer
+            # outputs, written once and read once) / 2 = 3.5 GB
+            gb_img = {("mobilenet", "source_only"): 1.39, ("mobilenet", "prototype_full"): 3.5}.get((args.backbone, args.workload))
+            if gb_img is not None:
+                gbs = line["value"] / world * gb_img
+                line["step_roofline"].update(algorithmic_gb_per_image=gb_img, achieved_gb_s_per_gpu=round(gbs, 1),
                                              hbm_frac=round(gbs / 8000.0, 4))
         if world == 1 and not args.no_cpu_baseline and not args.use_tn:
             line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size, args.backbone)
+        line["other_mfma"] = other
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -69,6 +69,12 @@ int uda_relayout_dw(const float* w, int C, float* out, void* stream);
  *   y[p,co] = bias[co] + addend[p,co] + sum_{t,ci} u(p+off_t, ci) * w[co][t][ci]
  * stats (optional, double[UDA_STAT_SLOTS][2][Cout], ADDED into): sum and sum of squares of y
  * before addend. */
+/* UDA_MFMA_F32: v_mfma_f32_32x32x2_f32, the exact fp32 fma chain.  UDA_MFMA_BF16X3: fp32 emulated on the bf16 matrix pipe:
+ * every operand is split exactly into three bf16 pieces (a = a1 + a2 + a3) and the six piece products down to 2^-24 relative
+ * are accumulated in fp32 (v_mfma_f32_32x32x16_bf16) - same fp32-level error as the fma chain (measured per call against
+ * float64 by tests/noise_report.py), 2.67x its matrix-pipe rate.  Inputs, outputs, accumulators and statistics stay fp32/fp64. */
+#define UDA_MFMA_F32 0
+#define UDA_MFMA_BF16X3 1
 typedef struct uda_conv_args {
     uda_src_t src;
     const float* w;        /* [Cout][row], the layout uda_relayout_ohwi writes */
@@ -82,8 +88,20 @@ typedef struct uda_conv_args {
     float* y;              /* [P, ldy] */
     int64_t ldy;
     double* stats;         /* [UDA_STAT_SLOTS][2][Cout] or NULL */
+    int32_t mfma;          /* UDA_MFMA_*: which matrix instructions the wide (MFMA-bound) tiles use; narrow kernels ignore it */
+    int32_t _pad3;
+    const void* x3_src;    /* UDA_MFMA_BF16X3, when uda_conv_uses_x3(a): src packed by uda_x3_pack (transform already applied) ... */
+    const void* x3_w;      /* ... and the weight rows w ([Cout] rows of the relayouted row length) packed by uda_x3_pack */
 } uda_conv_args_t;
+/* 1 when uda_conv_fwd will run these arguments on the bf16x3 wide-tile kernel and therefore needs x3_src / x3_w */
+int uda_conv_uses_x3(const uda_conv_args_t* a);
 int uda_conv_fwd(const uda_conv_args_t* a, void* stream);
+/* Operand packing for UDA_MFMA_BF16X3: every fp32 value as its three bf16 pieces, out[rows][ceil(C/16)][3][16] (96 contiguous
+ * bytes per row and 16-wide block), rows = N*H*W of src, values = the TRANSFORMED ones act(x*scale+shift)*mask*mask_scale, so a
+ * tensor is split once however many taps, workgroups or convolutions read it.  Weight rows: src with N = H = 1, W = rows,
+ * C = row length, no transform.  uda_x3_packed_bytes(rows, C): size of out. */
+uint64_t uda_x3_packed_bytes(int64_t rows, int K);
+int uda_x3_pack(const uda_src_t* src, void* out, void* stream);
 
 /* weight gradient of the same convolution: dw[co][ci][kh][kw] = sum_p dy[p,co]*u(p+off_t,ci) */
 typedef struct uda_wgrad_args {
@@ -95,6 +113,8 @@ typedef struct uda_wgrad_args {
     float* dw;             /* OIHW, contiguous */
     float* workspace;
     uint64_t workspace_bytes;
+    int32_t mfma;          /* UDA_MFMA_*, as in uda_conv_args_t */
+    int32_t _pad3;
 } uda_wgrad_args_t;
 uint64_t uda_conv_wgrad_workspace_bytes(int64_t P, int Cout, int Cin, int ksize);
 int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream);
@@ -256,9 +276,10 @@ int uda_feat_rank4(const float* wts, const float* coef, int64_t P, int C, float*
                    int accumulate, void* stream);
 
 /* ---- torch.optim.Adam update (no weight decay / amsgrad) over one flat fp32 buffer
- * (train_use_fix_initial.py:210-214) */
-int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                  float beta1, float beta2, float eps, int64_t step, void* stream);
+ * (train_use_fix_initial.py:210-214).  The hyper-parameters arrive as doubles: 1 - beta, lr / (1 - beta1^step) and
+ * sqrt(1 - beta2^step) are formed in double and rounded to fp32 where torch rounds them.  Used by uda_clr_amd.optim.FlatAdam. */
+int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, int64_t step, void* stream);
 
 /* ---- "bilinear upsample, then 3x3 conv" without the high-resolution GEMM (networks/decoder.py:50-53 feeding
  * last_conv_boundary[0], decoder.py:33): the channel mixing of the upsampled part commutes with the interpolation, so the

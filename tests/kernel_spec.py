@@ -581,7 +581,7 @@ class SpecKernels:
             d_feat.copy_(g)
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
-        exp_avg.mul_(beta1).add_(grads, alpha=1 - beta1)
+        exp_avg.lerp_(grads, 1 - beta1)
         exp_avg_sq.mul_(beta2).addcmul_(grads, grads, value=1 - beta2)
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         params.addcdiv_(exp_avg, exp_avg_sq.sqrt() / (bc2 ** 0.5) + eps, value=-lr / bc1)

@@ -16,6 +16,7 @@ struct ConvKArgs {
     double* stats; // [UDA_STAT_SLOTS][2][Cout] or null (fp64 atomics)
     int nMt, nNt;
     int debug;     // diagnostics only (UDA_WS_DEBUG): bit0 skip MFMAs, bit1 skip loader work
+    int x3;        // UDA_MFMA_BF16X3: wide tiles on the bf16 pipe by exact 3-way splitting (igemm_x3.hip)
 };
 
 struct WgradKArgs {
@@ -26,6 +27,7 @@ struct WgradKArgs {
     int cen;
     float* slab;      // [S][Cout][Jtot]
     int nCot, nJt, chunks_per_split, nchunks;
+    int x3;
 };
 
 #define IG_BK 32
@@ -34,3 +36,5 @@ struct WgradKArgs {
 
 int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st);          // 128 x {128,256} tiles
 int launch_wgrad_ws(WgradKArgs& k, int S, bool big, hipStream_t st);  // 128 x 128 or 256 x 256 tiles
+bool conv_x3_eligible(const ConvKArgs& k);
+int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st);   // bf16x3 forward / dgrad (igemm_x3.hip)

@@ -425,6 +425,24 @@ static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     return 0;
 }
 
+// true when uda_conv_fwd routes these arguments to the wide-tile (MFMA-bound) kernels
+static bool conv_is_wide(const uda_conv_args_t* a, int Kc, int Ktot) {
+    if (a->Cout == 1 && !a->src.scale && !a->src.mask && a->src.act == ACT_NONE && !a->stats && Ktot >= 1024) return false;
+    if (a->Cout <= 2 && a->ksize == 1 && !a->stats && Kc >= 64 && Kc <= 2048) return false;
+    if (a->Cout <= 96) return false;
+    if (Ktot <= 192 || (a->ksize >= 2 && Kc < IG_BK)) return false;
+    return true;
+}
+
+/* 1 when uda_conv_fwd will run these arguments on the bf16x3 wide-tile kernel, i.e. needs a->x3_src / a->x3_w (uda_x3_pack) */
+extern "C" int uda_conv_uses_x3(const uda_conv_args_t* a) {
+    if (!a || a->mfma != UDA_MFMA_BF16X3 || a->ksize < 1 || a->ksize > 3) return 0;
+    const int Kc = ((a->src.C + 3) / 4) * 4, Ktot = uda_k_row(a->src.C, a->ksize);
+    ConvKArgs k;
+    k.Kc = Kc; k.ksize = a->ksize; k.Cout = a->Cout;
+    return conv_is_wide(a, Kc, Ktot) && conv_x3_eligible(k) ? 1 : 0;
+}
+
 extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(a != nullptr, "uda_conv_fwd: null args");
@@ -451,6 +469,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.ldy = a->ldy;
     k.stats = a->stats;
     k.debug = 0;
+    k.x3 = a->mfma == UDA_MFMA_BF16X3;
     UDA_REQUIRE((P + 128) * a->src.ldx < ((int64_t)1 << 29) && (P + 128) * (a->src.mask ? a->src.ldm : 1) < ((int64_t)1 << 31),
                 "uda_conv_fwd: operand too large for 32-bit byte offsets (P * ld must stay below 2^29 elements)");
     int e;
@@ -477,7 +496,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
         else if (w128 <= w96) e = launch_conv<2, 2, 2, 2>(k, P, st);
         else e = launch_conv<1, 3, 4, 1>(k, P, st);
     }
-    else e = launch_conv_ws(k, P, st);
+    else e = (k.x3 && conv_x3_eligible(k)) ? launch_conv_x3(k, P, a->x3_src, a->x3_w, st) : launch_conv_ws(k, P, st);
     return e;
 }
 

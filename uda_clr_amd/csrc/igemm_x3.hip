@@ -1,0 +1,423 @@
+// fp32 implicit-GEMM convolution on the BF16 matrix pipe by exact three-way operand splitting ("bf16x3").
+//
+// gfx950 has no TF32 and its fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate.  Every fp32 value splits
+// EXACTLY into three bf16 pieces, a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2: 3 x 8 significand bits,
+// the residuals are exact in fp32), and every product of two pieces is exact in the fp32 accumulator of the bf16 MFMA.  Of the
+// nine piece products of a * b the six with i + j <= 4 are kept:
+//     a*b ~= a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1),      dropped terms <= 2^-24 |a b| (+ 2^-32): one fp32 rounding's worth,
+// so a dot product carries the same ~sqrt(K) * 2^-24 error as the fp32 fma chain it replaces (tests/bench_x3.py and
+// tests/noise_report.py measure both against float64).  Six v_mfma_f32_32x32x16_bf16 (32 cycles each) do the work of eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 2.67x the matrix-pipe rate for the same fp32-level result.  Inputs, outputs,
+// accumulators, BN statistics and the epilogue stay fp32 / fp64.
+//
+// Structure = igemm_ws.hip's (8 math waves + 4 loader waves, double-buffered LDS tile, one barrier per K-chunk, buffer-descriptor
+// operand loads with hardware zero-fill for out-of-image taps, XCD-chunked tile order), with these differences:
+//   * operands are split ONCE, by a packing pass (x3_pack_kernel: applies the pending BN / activation / dropout transform and
+//     writes the three pieces), not per tap and per workgroup: the first version split in the loader and was loader-bound at
+//     175-195 TF-equivalent; a 3x3 conv re-splits every activation nine times that way and every workgroup re-splits the weights;
+//   * the loader waves therefore only copy: one buffer_load_b128 + one ds_write_b128 per 16 bytes, no VALU but addresses;
+//   * a K-chunk is 16 deep (one bf16 MFMA k-step): tile = (BM + BN) rows x 112 B = 56 KiB for 256 x 256, two buffers;
+//   * the loader keeps TWO chunks of global loads in flight (two register sets): with one, its loads were issued only a barrier
+//     before they were needed and the kernel ran at the load latency (2.3 us per chunk against 1.5 us of MFMA work).
+#include "common.h"
+#include <stdlib.h>
+#include "igemm_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define X3_BK 16
+#define X3_ROW 56         // bf16 per staged row: 3 pieces x 16 + 8 pad = 112 B: a row's 96 B arrive as they lie in the packed operand
+                          // (linear, conflict-free ds_write_b128), and the fragment reads of 16 lanes (rows r, byte r*112 + q*32 + h*16)
+                          // fall on 64 distinct banks
+
+// Packed operand ("x3 layout"): per row (pixel, or weight row) and per 16-wide K block the three bf16 pieces, 96 contiguous bytes:
+//     element (row, k, piece q) at ((row * nb + k / 16) * 3 + q) * 16 + k % 16,   nb = K blocks per row.
+// Activations: k = channel (nb = ceil(C / 16)).  Weights: k = position in the tap-chunked K order of the fp32 layout.
+
+// (v0, v1) -> the three bf16 pieces of each, packed (v0 in the low half)
+__device__ __forceinline__ void x3_split2(float v0, float v1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    bf16x2 a = {(__bf16)v0, (__bf16)v1};                       // v_cvt_pk_bf16_f32 (round to nearest even)
+    p1 = __builtin_bit_cast(uint32_t, a);
+    const float r0 = v0 - __builtin_bit_cast(float, p1 << 16), r1 = v1 - __builtin_bit_cast(float, p1 & 0xffff0000u);   // exact
+    bf16x2 b = {(__bf16)r0, (__bf16)r1};
+    p2 = __builtin_bit_cast(uint32_t, b);
+    const float s0 = r0 - __builtin_bit_cast(float, p2 << 16), s1 = r1 - __builtin_bit_cast(float, p2 & 0xffff0000u);   // exact
+    bf16x2 c = {(__bf16)s0, (__bf16)s1};                       // s has <= 8 significant bits left: exact
+    p3 = __builtin_bit_cast(uint32_t, c);
+}
+
+// one thread: 8 consecutive k of one row -> 3 x 16 B.  XF as in the conv kernels (0 raw, 1 BN + act, 2 + keep-mask).
+struct X3PackArgs {
+    uda_src_t src;        // activations [P, ldx] with the pending transform; for weight rows: x = rows, C = Ktot, no transform
+    int64_t P;
+    int nb;               // 16-wide blocks per row
+    uint32_t* out;        // packed, [P][nb][3][16] bf16
+};
+
+template <int XF>
+__global__ __launch_bounds__(256) void x3_pack_kernel(X3PackArgs a) {
+    const int C = a.src.C, no = a.nb * 2;                        // octets per row
+    const int64_t total = a.P * no;
+    const float alo = a.src.act == ACT_NONE ? -INFINITY : 0.f, ahi = a.src.act == ACT_RELU6 ? 6.f : INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int o = (int)(e % no);
+        const int64_t p = e / no;
+        const int c0 = o * 8;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 4 * h;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) x = uda_ld4(a.src.x + p * a.src.ldx + c);          // rows hold round4(C) readable floats
+            float t[4] = {x.x, x.y, x.z, x.w};
+            if (XF >= 1) {
+                uint32_t mk = 0x01010101u;
+                if (XF == 2 && c < C) mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = (c + j) < C;
+                    const float sc = (ok && a.src.scale) ? a.src.scale[c + j] : 1.f, sh = (ok && a.src.shift) ? a.src.shift[c + j] : 0.f;
+                    float u = __builtin_amdgcn_fmed3f(t[j] * sc + sh, alo, ahi);
+                    if (XF == 2) u *= ((mk >> (8 * j)) & 0xffu) ? a.src.mask_scale : 0.f;
+                    t[j] = u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * h + j] = (c + j) < C ? t[j] : 0.f;
+        }
+        uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+        uint32_t* d = a.out + ((p * a.nb + (o >> 1)) * 3) * 8 + (o & 1) * 4;          // dwords: 8 per 16 bf16
+        *reinterpret_cast<uint4*>(d) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *reinterpret_cast<uint4*>(d + 8) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *reinterpret_cast<uint4*>(d + 16) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    }
+}
+
+struct X3KArgs {
+    const uint32_t* xa;   // packed activations [P][nbA][3][16]
+    const uint32_t* xw;   // packed weights [Cout][nchunks][3][16]
+    int N, H, W, nbA;
+    int Cout, ksize, dil, cen, nchunks;
+    const float* bias;
+    const float* addend;
+    int64_t ld_add;
+    float* y;
+    int64_t ldy;
+    double* stats;
+    int nMt, nNt;
+    int debug;            // diagnostics (UDA_X3_DEBUG): bit0 skip the MFMAs, bit1 skip the loader's global loads, bit2 skip its LDS writes
+};
+
+template <int KS, int TN, int BM>
+__global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
+    constexpr int MW = 8, BN = 64 * TN, TM = 2;
+    constexpr int WMM = BM / 64, WNN = MW / WMM, TNW = 2 * TN / WNN;
+    static_assert(WMM * WNN == MW && (2 * TN) % WNN == 0, "math-wave grid must tile the workgroup tile");
+    constexpr int NTHR = (MW + 4) * 64;
+    constexpr int A_U = BM * 6 / 256, B_U = BN * 6 / 256;        // 16-byte units (row, piece, octet) per loader thread and chunk
+    static_assert((BM * 6) % 256 == 0 && (BN * 6) % 256 == 0, "units must divide over the 256 loader threads");
+    constexpr int TILE = (BM + BN) * X3_ROW;                     // bf16 elements per buffer
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= MW;
+    const int lid = uda_xcd_remap(blockIdx.x, a.nMt * a.nNt);
+    const int mt = lid / a.nNt, nt = lid % a.nNt;
+    const int H = a.H, W = a.W;
+    const int64_t P = (int64_t)a.N * H * W;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const int nchunks = a.nchunks;
+    const int T = a.ksize * a.ksize;
+
+    // ------------------------------------------------------------------ loader state (global offsets in 16-byte units)
+    const int lt = (tid - MW * 64) & 255;
+    // unit u = lt + 256 * i -> (row = u / 6, part = u % 6); its LDS byte offset row * 112 + part * 16 = 16 * (u + row) is recomputed
+    // per use, the nine tap-validity bits of three units share one register: the loader's two register sets (96 VGPRs at
+    // 256 x 256) leave little room beside them
+    auto unit_row = [](int u) { return (u * 43691) >> 18; };    // u / 6 for u < 3072
+    int aoff[A_U], boff[B_U];
+    unsigned vmask3[(A_U + 2) / 3];
+    uint4 areg0[A_U], breg0[B_U], areg1[A_U], breg1[B_U];        // two chunks in flight (two register sets, statically indexed)
+    int t_cur = 0, blk = 0, half = 0, chunk = 0;
+    const int rowA16 = a.nbA * 6;                                // uint4 per packed activation row
+    if (loader) {
+#pragma unroll
+        for (int i = 0; i < (A_U + 2) / 3; ++i) vmask3[i] = 0;
+#pragma unroll
+        for (int i = 0; i < A_U; ++i) {
+            const int u = lt + 256 * i, row = unit_row(u), part = u - row * 6;
+            const int64_t p = m0 + row;
+            const bool ok = p < P;
+            const int q = ok ? (int)p : 0;
+            const int pw = q % W, ph = (q / W) % H;
+            aoff[i] = q * rowA16 + part;
+            unsigned vm = 0;
+            if (ok) {
+                if (KS == 3) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int th = a.ksize == 3 ? t / 3 : t / 2, tw = a.ksize == 3 ? t % 3 : t % 2;
+                        const int hh = ph + (th - a.cen) * a.dil, ww = pw + (tw - a.cen) * a.dil;
+                        vm |= (t < T && hh >= 0 && hh < H && ww >= 0 && ww < W ? 1u : 0u) << t;
+                    }
+                } else {
+                    vm = 1u;
+                }
+            }
+            vmask3[i / 3] |= vm << (9 * (i % 3));
+        }
+#pragma unroll
+        for (int i = 0; i < B_U; ++i) {
+            const int u = lt + 256 * i, row = unit_row(u), part = u - row * 6;
+            const int n = min(n0 + row, a.Cout - 1);
+            boff[i] = n * (nchunks * 6) + part;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(a.xa), 0, (int)min((int64_t)0x7fffffff, P * rowA16 * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(a.xw), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.Cout * nchunks * 96), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+
+    auto issue = [&](uint4 (&ar)[A_U], uint4 (&br)[B_U]) {
+        const int t = t_cur, b16 = blk + half;
+        const bool kval = b16 < a.nbA;
+        int tapoff = 0;
+        if (KS == 3) {
+            const int th = a.ksize == 3 ? t / 3 : t >> 1;
+            tapoff = ((th - a.cen) * W + (t - th * a.ksize - a.cen)) * a.dil;
+        }
+        const int xoff = tapoff * rowA16 + b16 * 6;
+#pragma unroll
+        for (int i = 0; i < A_U; ++i) {
+            const bool ok = kval && ((vmask3[i / 3] >> (9 * (i % 3) + (KS == 3 ? t : 0))) & 1u);
+            ar[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (aoff[i] + xoff) * 16 : OOB, 0, 0));
+        }
+        const int woff = chunk * 6;
+#pragma unroll
+        for (int i = 0; i < B_U; ++i)
+            br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, (boff[i] + woff) * 16, 0, 0));
+        ++chunk;
+        if (KS == 3) {          // halves of a 32-channel slice share the tap; then the next tap; after T taps the next slice
+            if ((half ^= 1) == 0 && ++t_cur == T) {
+                t_cur = 0;
+                blk += 2;
+            }
+        } else {
+            blk += 1;
+        }
+    };
+
+    auto stage = [&](const uint4 (&ar)[A_U], const uint4 (&br)[B_U], __bf16* buf) {
+        char* As = reinterpret_cast<char*>(buf);                       // [BM][X3_ROW]
+        char* Bs = As + BM * X3_ROW * 2;                               // [BN][X3_ROW]
+#pragma unroll
+        for (int i = 0; i < A_U; ++i) *reinterpret_cast<uint4*>(As + 16 * (lt + 256 * i + unit_row(lt + 256 * i))) = ar[i];
+#pragma unroll
+        for (int i = 0; i < B_U; ++i) *reinterpret_cast<uint4*>(Bs + 16 * (lt + 256 * i + unit_row(lt + 256 * i))) = br[i];
+    };
+
+    // ------------------------------------------------------------------ math state
+    const int wm = (wave / WNN) % WMM, wn = wave % WNN;
+    const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TNW) + (lane & 31);
+    const int koff = 8 * (lane >> 5);
+
+    float s1[TNW], s2[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) s1[j] = s2[j] = 0.f;
+    if (loader) {
+        // chunk c lives in register set c & 1 and in LDS buffer c & 1; chunks c + 1 and c + 2 are in flight while chunk c is computed
+        issue(areg0, breg0);
+        if (nchunks > 1) issue(areg1, breg1);
+        stage(areg0, breg0, smem16);
+        if (nchunks > 2) issue(areg0, breg0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 1 < nchunks) {
+                if (!(a.debug & 4)) stage(areg1, breg1, smem16 + TILE);
+                if (c + 3 < nchunks && !(a.debug & 2)) issue(areg1, breg1);
+            }
+            __syncthreads();
+            if (c + 1 < nchunks) {
+                if (c + 2 < nchunks) {
+                    if (!(a.debug & 4)) stage(areg0, breg0, smem16);
+                    if (c + 4 < nchunks && !(a.debug & 2)) issue(areg0, breg0);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        f32x16 acc[TM][TNW];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(1);
+        for (int c = 0; c < nchunks; ++c) {
+            if (a.debug & 1) {
+                __syncthreads();
+                continue;
+            }
+            const __bf16* As = smem16 + (c & 1) * TILE;
+            const __bf16* Bs = As + BM * X3_ROW;
+            // one A row-block at a time (12 fragment registers beside the 16 * TM * TNW accumulators: the 256 x 256 tile has 128
+            // of them and 3 waves per SIMD leave 168 registers per wave); B fragments are re-read per row-block (LDS reads: 0.3
+            // ds_read_b128 per MFMA, far below the 2 per MFMA gap the LDS sustains)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[q] = *reinterpret_cast<const bf16x8*>(&As[(arow + 32 * i) * X3_ROW + q * 16 + koff]);
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) {
+                    // keep the scheduler from hoisting every block's fragment reads above the MFMAs (it would hold 3 * TNW fragments
+                    // live and spill); the exposed LDS latency of one block is covered by the SIMD's other math wave
+                    if (BM == 256) asm volatile("" ::: "memory");
+                    bf16x8 bq[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + 32 * j) * X3_ROW + q * 16 + koff]);
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bq[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bq[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bq[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[0], acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const int colb = n0 + wn * (32 * TNW) + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int col = colb + 32 * j;
+            const bool cok = col < a.Cout;
+            const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (cok && row < P) {
+                        float v = acc[i][j][r] + bv;
+                        s1[j] += v;
+                        s2[j] += v * v;
+                        if (a.addend) v += a.addend[row * a.ld_add + col];
+                        a.y[row * a.ldy + col] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats) {           // uniform over the workgroup
+        float* red = reinterpret_cast<float*>(smem16);   // [WMM][2][BN]
+        if (!loader) {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+                const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+                if (lane < 32) {
+                    const int cl = wn * (32 * TNW) + 32 * j + lane;
+                    red[(wm * 2 + 0) * BN + cl] = t1;
+                    red[(wm * 2 + 1) * BN + cl] = t2;
+                }
+            }
+        }
+        __syncthreads();
+        double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
+        for (int e = tid; e < 2 * BN; e += NTHR) {
+            const int qd = e / BN, cl = e % BN;
+            if (n0 + cl < a.Cout) {
+                float t = 0.f;
+#pragma unroll
+                for (int m = 0; m < WMM; ++m) t += red[(m * 2 + qd) * BN + cl];
+                atomicAdd(&dst[qd * a.Cout + n0 + cl], (double)t);
+            }
+        }
+    }
+}
+
+template <int KS, int TN, int BM>
+static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st) {
+    constexpr int BN = 64 * TN;
+    constexpr size_t lds = 2 * (BM + BN) * X3_ROW * sizeof(__bf16);
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static bool configured = false;
+    auto fn = igemm_conv_x3_kernel<KS, TN, BM>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return uda_set_error("igemm_conv_x3: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        configured = true;
+    }
+    k.nMt = uda_cdiv(P, BM);
+    k.nNt = uda_cdiv(k.Cout, BN);
+    static const int dbg = getenv("UDA_X3_DEBUG") ? atoi(getenv("UDA_X3_DEBUG")) : 0;
+    k.debug = dbg;
+    hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3(768), lds, st, k);
+    UDA_LAUNCH_CHECK("igemm_conv_x3");
+    return 0;
+}
+
+// Eligibility: the tap-chunked K order (>= 32 channels per tap), and enough MFMA work per packed element to pay for the packing
+// pass (2 * Cout * taps FLOPs per activation element): the multi-tap convs with Cout * taps >= 768 (measured: 3x3 / 2x2 convs with
+// 256 outputs run 1.5-1.7x faster incl. the pass, a 1x1 1280 -> 256 conv 0.8x).
+bool conv_x3_eligible(const ConvKArgs& k) { return k.Kc >= IG_BK && k.ksize >= 2 && k.Cout * k.ksize * k.ksize >= 768; }
+
+static inline int x3_nb(int C) { return uda_cdiv(C, X3_BK); }
+
+// bytes of a packed operand with `rows` rows of K values
+extern "C" uint64_t uda_x3_packed_bytes(int64_t rows, int K) { return (uint64_t)rows * x3_nb(K) * 96 + 64; }
+
+/* Pack (split) an operand for the bf16x3 kernels: out[rows][ceil(C/16)][3][16] bf16 of the TRANSFORMED values
+ * act(x * scale + shift) * mask * mask_scale (rows = N*H*W).  Weight rows: a src with N = H = 1, W = rows, C = K, no transform. */
+extern "C" int uda_x3_pack(const uda_src_t* src, void* out, void* stream) {
+    UDA_REQUIRE(src && src->x && out && uda_aligned16(out) && uda_aligned16(src->x) && src->ldx % 4 == 0 && src->C > 0,
+                "uda_x3_pack: bad args (16-byte aligned rows)");
+    hipStream_t st = (hipStream_t)stream;
+    X3PackArgs pa;
+    pa.src = *src; pa.P = (int64_t)src->N * src->H * src->W; pa.nb = x3_nb(src->C); pa.out = reinterpret_cast<uint32_t*>(out);
+    UDA_REQUIRE(pa.P > 0, "uda_x3_pack: empty operand");
+    const int64_t tot = pa.P * pa.nb * 2;
+    const int grid = (int)(uda_cdiv(tot, 256) > 65536 ? 65536 : uda_cdiv(tot, 256));
+    if (src->mask) hipLaunchKernelGGL(x3_pack_kernel<2>, dim3(grid), dim3(256), 0, st, pa);
+    else if (src->scale || src->act != ACT_NONE) hipLaunchKernelGGL(x3_pack_kernel<1>, dim3(grid), dim3(256), 0, st, pa);
+    else hipLaunchKernelGGL(x3_pack_kernel<0>, dim3(grid), dim3(256), 0, st, pa);
+    UDA_LAUNCH_CHECK("x3_pack");
+    return 0;
+}
+
+int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st) {
+    const int64_t lim = (int64_t)1 << 31;
+    const int nbA = x3_nb(k.src.C), nch = uda_cdiv(k.Ktot, X3_BK);
+    UDA_REQUIRE(x3_src && x3_w && uda_aligned16(x3_src) && uda_aligned16(x3_w),
+                "uda_conv_fwd (bf16x3): the packed operands x3_src / x3_w are missing (uda_x3_pack; uda_conv_uses_x3 tells when they are needed)");
+    UDA_REQUIRE((P + 256) * nbA * 6 < lim / 16 && (int64_t)(k.Cout + 320) * nch * 6 < lim / 16,
+                "uda_conv_fwd (bf16x3): operand too large for the 32-bit offsets of the wide-tile kernel");
+    X3KArgs x;
+    x.xa = reinterpret_cast<const uint32_t*>(x3_src); x.xw = reinterpret_cast<const uint32_t*>(x3_w);
+    x.N = k.src.N; x.H = k.src.H; x.W = k.src.W; x.nbA = nbA;
+    x.Cout = k.Cout; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen; x.nchunks = nch;
+    x.bias = k.bias; x.addend = k.addend; x.ld_add = k.ld_add; x.y = k.y; x.ldy = k.ldy; x.stats = k.stats;
+    // 256 x 256 tiles once they fill the chip twice over; 128 x 256 for wide outputs on fewer pixels; 128 x 128 otherwise
+    const bool wide = k.Cout > 128;
+    const bool tall = wide && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
+    const bool mid = wide && uda_cdiv(P, 128) * uda_cdiv(k.Cout, 256) >= 256;
+    if (k.ksize >= 2) {
+        if (tall) return launch_x3<3, 4, 256>(x, P, st);
+        if (mid) return launch_x3<3, 4, 128>(x, P, st);
+        return launch_x3<3, 2, 128>(x, P, st);
+    }
+    if (tall) return launch_x3<1, 4, 256>(x, P, st);
+    if (mid) return launch_x3<1, 4, 128>(x, P, st);
+    return launch_x3<1, 2, 128>(x, P, st);
+}

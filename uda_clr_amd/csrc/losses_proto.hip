@@ -418,28 +418,29 @@ extern "C" int uda_feat_rank4(const float* wts, const float* coef, int64_t P, in
 }
 
 // ------------------------------------------------------------------------------------------ fused Adam
-// torch.optim.Adam (no weight decay, no amsgrad) over one flat fp32 buffer:
-//   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// torch.optim.Adam (no weight decay, no amsgrad) over one flat fp32 buffer, with the scalars rounded where torch rounds them
+// (python doubles 1 - beta, lr / bias_correction1, sqrt(bias_correction2) cast to fp32 when they meet the tensors):
+//   m = m + (1-b1) * (g - m)   [lerp];   v = b2 * v + (1-b2) * g * g;   p -= (lr/bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2_sqrt) {
+                                                   float* __restrict__ v, int64_t n, float step_size, float w1, float b2, float w2,
+                                                   float eps, float bc2_sqrt) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const float step_size = lr / bc1;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const float gg = g[e];
-        const float mm = b1 * m[e] + (1.f - b1) * gg;
-        const float vv = b2 * v[e] + (1.f - b2) * gg * gg;
+        const float m0 = m[e];
+        const float mm = m0 + w1 * (gg - m0);
+        const float vv = b2 * v[e] + w2 * gg * gg;
         m[e] = mm;
         v[e] = vv;
-        p[e] -= step_size * mm / (sqrtf(vv) / bc2_sqrt + eps);
+        p[e] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     }
 }
-extern "C" int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                             float beta1, float beta2, float eps, int64_t step, void* stream) {
+extern "C" int uda_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                             double beta1, double beta2, double eps, int64_t step, void* stream) {
     UDA_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "uda_adam_step: bad args");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2));
     UDA_LAUNCH_CHECK("adam");
     return 0;
 }

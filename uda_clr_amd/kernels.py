@@ -30,13 +30,14 @@ class UdaSrc(C.Structure):
 class UdaConvArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("w", C.c_void_p), ("Cout", C.c_int32), ("ksize", C.c_int32),
                 ("dil", C.c_int32), ("origin", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
-                ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p)]
+                ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p),
+                ("mfma", C.c_int32), ("_pad3", C.c_int32), ("x3_src", C.c_void_p), ("x3_w", C.c_void_p)]
 
 
 class UdaWgradArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("dy", C.c_void_p), ("lddy", C.c_int64), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("dil", C.c_int32), ("origin", C.c_int32), ("dw", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64), ("mfma", C.c_int32), ("_pad3", C.c_int32)]
 
 
 # every symbol declared in include/uda_clr_hip.h: name -> (restype, argtypes)
@@ -48,6 +49,9 @@ SYMBOLS = {
     "uda_relayout_dgrad": (_I, [_P, _I, _I, _I, _P, _P]),
     "uda_relayout_dw": (_I, [_P, _I, _P, _P]),
     "uda_conv_fwd": (_I, [C.POINTER(UdaConvArgs), _P]),
+    "uda_conv_uses_x3": (_I, [C.POINTER(UdaConvArgs)]),
+    "uda_x3_packed_bytes": (_U, [_L, _I]),
+    "uda_x3_pack": (_I, [C.POINTER(UdaSrc), _P, _P]),
     "uda_conv_wgrad_workspace_bytes": (_U, [_L, _I, _I, _I]),
     "uda_conv_wgrad": (_I, [C.POINTER(UdaWgradArgs), _P]),
     "uda_dwconv_workspace_bytes": (_U, [_L, _I]),
@@ -96,7 +100,7 @@ SYMBOLS = {
     "uda_proto_bwd": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "uda_feat_dot4": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "uda_feat_rank4": (_I, [_P, _P, _L, _I, _P, _L, _I, _P]),
-    "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
+    "uda_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _L, _P]),
     "uda_proto_align_fwd": (_I, [_P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P]),
     "uda_proto_align_bwd": (_I, [_P, _P, _P, _F, _F, _I, _P, _P, _P]),
     "uda_adv_loss_fwd": (_I, [_P, _I, _P, _I, _F, _F, _P, _P]),
@@ -151,8 +155,18 @@ def _mat(t: torch.Tensor, name="tensor"):
 class HipKernels:
     name = "hip"
 
-    def __init__(self):
+    MFMA_F32, MFMA_BF16X3 = 0, 1
+
+    def __init__(self, mfma=None):
         self.lib = load_library()
+        # matrix instructions of the wide (MFMA-bound) conv tiles (UDA_CLR_MFMA, include/uda_clr_hip.h UDA_MFMA_*):
+        #   "bf16x3" (default) = fp32 emulated on the bf16 pipe by exact 3-way operand splitting - fp32-level results (per-call
+        #             error against float64 equal to the fp32 kernel's, tests/bench_x3.py), 1.5-1.7x the fp32-MFMA kernel's rate;
+        #   "f32"    = v_mfma_f32_32x32x2_f32, the exact fp32 fma chain.
+        mode = (mfma or os.environ.get("UDA_CLR_MFMA", "bf16x3")).lower()
+        if mode not in ("f32", "bf16x3"):
+            raise ValueError("UDA_CLR_MFMA must be 'f32' or 'bf16x3', got %r" % mode)
+        self.mfma = self.MFMA_BF16X3 if mode == "bf16x3" else self.MFMA_F32
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -232,7 +246,40 @@ class HipKernels:
         if stats is not None:
             assert stats.dtype == torch.float64 and stats.is_contiguous() and tuple(stats.shape) == (STAT_SLOTS, 2, Cout)
         a.stats = _ptr(stats)
+        a.mfma = self.mfma
+        if self.mfma != self.MFMA_F32 and self.lib.uda_conv_uses_x3(C.byref(a)):
+            # bf16x3: both operands as their three bf16 pieces.  The packed forms are kept on the descriptor / the relayouted
+            # weight, so an activation read by several convolutions (the ASPP input) and a weight used by several passes of one
+            # step are split once.
+            xs = getattr(src, "_x3", None)
+            if xs is None:
+                xs = self.x3_pack(a.src, src.P, src.C, out.device)
+                src._x3 = xs
+            xw = getattr(w, "_x3", None)
+            if xw is None:
+                xw = self.x3_pack_rows(w)
+                w._x3 = xw
+            a.x3_src, a.x3_w = xs.data_ptr(), xw.data_ptr()
+            return self._conv_x3(a)
         self._ck(self.lib.uda_conv_fwd(C.byref(a), self._stream()))
+
+    def _conv_x3(self, a):
+        """the bf16x3 GEMM launch alone (bench.py times this)"""
+        self._ck(self.lib.uda_conv_fwd(C.byref(a), self._stream()))
+
+    def x3_pack(self, usrc: UdaSrc, rows, K, device):
+        out = torch.empty(int(self.lib.uda_x3_packed_bytes(rows, K)), dtype=torch.uint8, device=device)
+        self._ck(self.lib.uda_x3_pack(C.byref(usrc), out.data_ptr(), self._stream()))
+        return out
+
+    def x3_pack_rows(self, w):
+        """a relayouted weight [rows, taps, K'] (contiguous rows) as packed rows"""
+        rows, klen = w.shape[0], w.numel() // w.shape[0]
+        s = UdaSrc()
+        s.x, s.ldx, s.N, s.H, s.W, s.C = w.data_ptr(), klen, 1, 1, rows, klen
+        s.scale = s.shift = s.mask = None
+        s.act, s.ldm, s.mask_scale = 0, 0, 1.0
+        return self.x3_pack(s, rows, klen, w.device)
 
     def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
         a = UdaWgradArgs()
@@ -245,6 +292,7 @@ class HipKernels:
         a.dw = dw.data_ptr()
         ws = self._ws(dy, self.lib.uda_conv_wgrad_workspace_bytes(src.P, Cout, src.C, ksize))
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.mfma = self.mfma
         self._ck(self.lib.uda_conv_wgrad(C.byref(a), self._stream()))
 
     # ------------------------------------------------------------------ depthwise

@@ -206,10 +206,13 @@ int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* 
 /* g = dU*mask*act'(a);  sums (double[UDA_STAT_SLOTS][3][C], ADDED into) = (sum g, sum g*xhat, sum dU) */
 int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
                      const float* invstd, double* sums, void* stream);
-/* sums: double[UDA_STAT_SLOTS][3][C] */
+/* sums: double[UDA_STAT_SLOTS][3][C].  count = elements per channel of the batch statistics; +infinity for a FROZEN
+ * (eval-mode) BatchNorm, DeepLab.freeze_bn() of deeplabv3.py:43-50: c1 = c2 = 0, dx = scale * g, dgamma / dbeta as usual with
+ * mean / invstd = the running statistics.  q1_total ([C] or NULL = 0): sum of the upstream gradient over ALL positions of the
+ * zero-padded block input (quirk Q1) - needed when the depthwise BatchNorm behind this one is frozen. */
 int uda_bnbwd_finalize(const double* sums, int C, double count, int q1_border, int act,
-                       const float* shift, const float* mean, const float* invstd, float* c1,
-                       float* c2, float* dgamma, float* dbeta, void* stream);
+                       const float* shift, const float* mean, const float* invstd, const float* q1_total,
+                       float* c1, float* c2, float* dgamma, float* dbeta, void* stream);
 /* out = addend + scale*(g - c1 - xhat*c2) */
 int uda_bnbwd_apply(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
                     const float* invstd, const float* c1, const float* c2, const float* addend,

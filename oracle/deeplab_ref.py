@@ -58,8 +58,10 @@ def mbv2_blocks(output_stride=16):
 
 
 class _Ctx:
-    def __init__(self, sd, training, masks, record):
+    def __init__(self, sd, training, masks, record, bn_training=None):
         self.sd, self.training, self.masks, self.record = sd, training, masks, record
+        # DeepLab.freeze_bn() (deeplabv3.py:43-50) puts the BatchNorm modules in eval mode while the model (dropout) keeps training
+        self.bn_training = training if bn_training is None else bn_training
 
     def transnorm(self, x, prefix):
         """TransNorm (``--use_TN``; networks/sync_batchnorm/batchnorm.py:436-520).  Training: the first
@@ -73,7 +75,7 @@ class _Ctx:
         rms, rvs = sd[prefix + ".running_mean_source"], sd[prefix + ".running_var_source"]
         rmt, rvt = sd[prefix + ".running_mean_target"], sd[prefix + ".running_var_target"]
         C = x.shape[1]
-        if self.training:
+        if self.bn_training:
             sd[prefix + ".num_batches_tracked"] += 1
             n0 = x.shape[0] // 2
             halves = (x[:n0], x[n0:])
@@ -96,11 +98,11 @@ class _Ctx:
         sd = self.sd
         if (prefix + ".running_mean_source") in sd:
             return self.transnorm(x, prefix)
-        if self.training and (prefix + ".num_batches_tracked") in sd:
+        if self.bn_training and (prefix + ".num_batches_tracked") in sd:
             sd[prefix + ".num_batches_tracked"] += 1
         return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
                             sd[prefix + ".weight"], sd[prefix + ".bias"],
-                            self.training, BN_MOMENTUM, BN_EPS)
+                            self.bn_training, BN_MOMENTUM, BN_EPS)
 
     def dropout(self, x, name, p):
         if not self.training:
@@ -192,14 +194,14 @@ def _mobilenet_backbone(c, x, output_stride):
     return h, low
 
 
-def deeplab_forward(sd, x, training=True, masks=None, record=None, output_stride=16):
+def deeplab_forward(sd, x, training=True, masks=None, record=None, output_stride=16, bn_training=None):
     """Returns (x1, x2, feature, x_bu_feature, x_feature, x1_before, x2_before).
 
     ``sd`` maps reference state-dict keys to tensors; BN running stats in it are
     updated in place when ``training`` (deeplabv3.py:32-41).  The backbone is told
     from the keys (``backbone.conv1.weight`` exists only in the ResNet).
     """
-    c = _Ctx(sd, training, masks, record)
+    c = _Ctx(sd, training, masks, record, bn_training)
     if "backbone.conv1.weight" in sd:
         h, low = _resnet_backbone(c, x, output_stride)
     else:

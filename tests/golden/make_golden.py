@@ -19,6 +19,7 @@ inputs and stores inputs' seeds + expected outputs as small data files:
   metrics.json           dice_coeff_2label / pixel_acc on seeded logits
   trainer_*.json         loss rows written by the reference's own Trainer loops
   input_pipeline.json, input_pipeline_small.npz   outputs of the reference's dataloaders/custom_transforms.py on seeded samples
+  forward_frozen_64.npz  DeepLab(freeze_bn=True) in training mode (eval-mode BatchNorm, live dropout): outputs, loss, gradient norms
 
 While generating, every fixture is also compared with the oracle restatement (oracle/), so a
 successful run pins the oracle against the reference on full tensors, not only on the samples
@@ -210,6 +211,65 @@ def make_forward(m, B, S, tag):
         out["mask." + k + ".sum"] = np.int64(v.sum().item())
     m.load_state_dict(sd0)
     np.savez_compressed(os.path.join(HERE, "forward_%s.npz" % tag), **out)
+
+
+def make_frozen(B=2, S=64):
+    """DeepLab(freeze_bn=True) (deeplabv3.py:43-50; train_use_fix_initial.py:92-96 turns any --freeze-bn value into True): the
+    BatchNorm modules sit in eval mode (running statistics normalise, nothing is updated) while the model itself trains -
+    dropout active, gamma / beta and all weights receive gradients.  Running statistics and affine parameters are perturbed
+    (seeded) so the frozen statistics differ from the batch's."""
+    from networks.deeplabv3 import DeepLab
+    from oracle import deeplab_ref, step_ref
+    torch.manual_seed(1337)
+    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True, freeze_bn=True, method="prototype_full")
+    g = torch.Generator().manual_seed(5)
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        elif k.endswith("running_var"):
+            v.copy_(0.5 + torch.rand(v.shape, generator=g))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            assert not mod.training
+            mod.weight.data.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    assert m.training
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    out = {"B": B, "S": S, "input_seed": 0, "dropout_seed": 7, "target_seed": 11, "perturb_seed": 5}
+    torch.manual_seed(0)
+    x = torch.randn(B, 3, S, S)
+    tmap, tbd = synth_targets(B, S, S, 11)
+    torch.manual_seed(7)
+    ref = m(x)
+    loss = torch.nn.BCELoss()(torch.sigmoid(ref[0]), tmap) + torch.nn.MSELoss()(torch.sigmoid(ref[1]), tbd)
+    loss.backward()
+    osd = deeplab_ref.canonical_state(sd0, requires_grad=True)
+    rec = {}
+    torch.manual_seed(7)
+    mine = deeplab_ref.deeplab_forward(osd, x, training=True, record=rec, bn_training=False)
+    oloss = step_ref.seg_loss(mine[0], mine[1], tmap, tbd)
+    oloss.backward()
+    for n, r, o in zip(NAMES, ref, mine):
+        summarize("train." + n, r, out)
+        check("frozen train " + n, o, r)
+    check("frozen train loss", oloss, loss, 1e-6)
+    out["train.loss"] = np.float64(loss.item())
+    gn, keys = [], []
+    for k, p in m.named_parameters():
+        if ".low_level_features." in k or ".high_level_features." in k:
+            continue
+        keys.append(k)
+        gn.append(p.grad.double().norm().item())
+        check("frozen grad " + k, osd[k].grad, p.grad, 2e-4)
+    out["train.grad_norm"] = np.array(gn)
+    out["train.grad_keys"] = np.array(keys)
+    rs = m.state_dict()
+    for k in rs:
+        if k.rsplit(".", 1)[-1].startswith(("running_", "num_batches")):
+            assert torch.equal(rs[k], sd0[k]), "frozen statistics moved: " + k
+    for k, v in rec.items():
+        out["mask." + k + ".sum"] = np.int64(v.sum().item())
+    np.savez_compressed(os.path.join(HERE, "forward_frozen_%d.npz" % S), **out)
 
 
 def make_proto():
@@ -523,7 +583,11 @@ def make_input_pipeline():
 if __name__ == "__main__":
     import tempfile
     install_reference()
-    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tb256", "tp", "rn", "tn", "input"]
+    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tb256", "tp", "rn", "tn", "input", "frozen"]
+    if "frozen" in which:
+        make_frozen()
+        if which == ["frozen"]:
+            raise SystemExit(0)
     if "input" in which:
         make_input_pipeline()
         if which == ["input"]:

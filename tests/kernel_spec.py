@@ -361,7 +361,7 @@ class SpecKernels:
         sums[0, 1] += (g.double() * xhat.double()).sum(0)
         sums[0, 2] += dU.double().sum(0)
 
-    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
+    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta, q1_total=None):
         """Adds the border term of quirk Q1 when y.bn.q1_border, then c1 = sum g / n,
         c2 = sum g*xhat / n, dgamma = sum g*xhat, dbeta = sum g."""
         sums = sums.sum(0)
@@ -370,7 +370,7 @@ class SpecKernels:
             sh = y.shift.double()
             gate = torch.ones_like(sh) if y.act == ACT_NONE else (
                 (sh > 0).double() if y.act == ACT_RELU else ((sh > 0) & (sh < 6)).double())
-            gb = -sums[2] * gate
+            gb = ((0.0 if q1_total is None else q1_total.double()) - sums[2]) * gate      # q1_total: frozen depthwise BN behind
             sg = sg + gb
             sgx = sgx + gb * (-y.bn.mean.double() * y.bn.invstd.double())
         c1.copy_((sg / y.bn.count).float())

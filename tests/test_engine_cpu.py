@@ -249,3 +249,36 @@ def test_mc_fast_path_refuses_stale_activations():
     m(x)
     m.mc_dropout_logits(x, passes=1, reps=2)
     assert len(calls) == 2
+
+
+def test_frozen_batchnorm_training_matches_oracle_and_reference_fixture(golden_dir):
+    """DeepLab.freeze_bn() while training (deeplabv3.py:43-50; train_use_fix_initial.py:92-96 makes ANY --freeze-bn value True):
+    running statistics normalise and stay put, dropout is live, gamma / beta / weights receive gradients - incl. the quirk-Q1
+    border term with a frozen depthwise BN behind it.  (1) the oracle's frozen mode reproduces the fixture the reference's own
+    DeepLab(freeze_bn=True) wrote (forward_frozen_64.npz); (2) the engine (torch statement of the kernels) against the fp64
+    oracle (model_cases.frozen_grads_ok: without batch statistics the fp32 noise floor is ~1e-5, and what remains are ReLU gates
+    within rounding of 0 - one flipped gate in the ASPP moves every backbone gradient by 0.05-0.5 %)."""
+    import os
+    import numpy as np
+    from make_golden_inputs import synth_targets
+    z = np.load(os.path.join(golden_dir, "forward_frozen_64.npz"))
+    B, S = int(z["B"]), int(z["S"])
+    m = _model()                      # perturbed exactly like the fixture's model (generator seed 5, same draw order)
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    osd = deeplab_ref.canonical_state({k: v.clone() for k, v in m.state_dict().items()}, requires_grad=True)
+    torch.manual_seed(int(z["dropout_seed"]))
+    ref = deeplab_ref.deeplab_forward(osd, x, training=True, bn_training=False)
+    loss_ref = step_ref.seg_loss(ref[0], ref[1], tmap, tbd)
+    loss_ref.backward()
+    assert abs(loss_ref.item() - float(z["train.loss"])) < 1e-6
+    keys = [str(k) for k in z["train.grad_keys"]]
+    np.testing.assert_allclose([osd[k].grad.double().norm().item() for k in keys], z["train.grad_norm"], rtol=1e-4)
+    # (2)
+    from kernel_spec import SpecKernels
+    from uda_clr_amd.engine import GeneratorEngine
+    fwd, grads, stats, _ = model_cases.train_parity(torch.device("cpu"), frozen_bn=True, engine=GeneratorEngine(SpecKernels()), seed=11)
+    assert max(fwd.values()) < 2e-4, fwd
+    assert stats == 0.0               # frozen statistics: bit-identical to where they started
+    model_cases.frozen_grads_ok(grads)

@@ -287,3 +287,42 @@ def test_nan_in_the_input_raises_in_the_trainer_although_the_clamps_swallow_it(t
                                   batch_size=2, warmup_epoch=-1)
     with pytest.raises(ValueError, match="nan"):
         tr.train_epoch()
+
+
+def test_frozen_batchnorm_training_matches_oracle_and_reference_fixture():
+    """DeepLab.freeze_bn() while training (deeplabv3.py:43-50) on the HIP kernels: eval-mode BatchNorm backward
+    (uda_bnbwd_finalize with count = inf, the quirk-Q1 border total handed in), live dropout; against the fp64 oracle and
+    against the fixture the reference's own DeepLab(freeze_bn=True) wrote (forward_frozen_64.npz)."""
+    import os
+    import numpy as np
+    from make_golden_inputs import synth_targets
+    from oracle import deeplab_ref, step_ref
+    fwd, grads, stats, _ = model_cases.train_parity(DEV, frozen_bn=True, seed=11)
+    assert max(fwd.values()) < 1e-3, fwd
+    assert stats == 0.0
+    model_cases.frozen_grads_ok(grads)
+    z = np.load(os.path.join(model_cases.GOLDEN, "forward_frozen_64.npz"))
+    B, S = int(z["B"]), int(z["S"])
+    m = model_cases.seeded_model(perturb=True).train()       # the fixture's seeded perturbation (generator seed 5, same draw order)
+    m.freeze_bn()
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    rec = {}
+    torch.manual_seed(int(z["dropout_seed"]))
+    with torch.no_grad():
+        deeplab_ref.deeplab_forward(deeplab_ref.canonical_state({k: v.clone() for k, v in m.state_dict().items()}), x, training=True,
+                                    record=rec, bn_training=False)
+    m.to(DEV)
+    m.set_dropout_masks(rec)
+    out = m(x.to(DEV))
+    loss = step_ref.seg_loss(out[0], out[1], tmap.to(DEV), tbd.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-3 * float(z["train.loss"])
+    for n, t in zip(model_cases.NAMES, out):
+        a = t.detach().double().abs().sum().item()
+        assert abs(a - float(z["train.%s.abs" % n])) < 1e-3 * float(z["train.%s.abs" % n]), n
+    live = m._flat_state()
+    gn = np.array([live[str(k)].grad.double().norm().item() for k in z["train.grad_keys"]])
+    rel_gn = np.abs(gn - z["train.grad_norm"]) / np.maximum(z["train.grad_norm"], 1e-12)
+    assert rel_gn.max() < 1e-2 and np.median(rel_gn) < 5e-4, (rel_gn.max(), np.median(rel_gn))

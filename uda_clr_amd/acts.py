@@ -36,6 +36,8 @@ class BNRec:
     count: float                   # elements per channel the statistics were taken over
     q1_border: bool = False        # statistics include the zero border of quirk Q1
     gain: Optional[torch.Tensor] = None     # TransNorm: [C] factor 1 + alpha already folded into scale / shift
+    frozen: bool = False           # eval-mode BN inside a training pass (freeze_bn): mean / invstd are the RUNNING statistics,
+                                   # count = inf (no batch-statistics terms in the backward)
 
 
 @dataclass

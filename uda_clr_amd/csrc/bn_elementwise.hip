@@ -465,7 +465,8 @@ extern "C" int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y
 // ------------------------------------------------------------------------------------------
 __global__ void bnbwd_finalize_kernel(const double* __restrict__ sums, int C, double count, int q1, int act,
                                       const float* __restrict__ shift, const float* __restrict__ mean,
-                                      const float* __restrict__ invstd, float* __restrict__ c1, float* __restrict__ c2,
+                                      const float* __restrict__ invstd, const float* __restrict__ q1_total,
+                                      float* __restrict__ c1, float* __restrict__ c2,
                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -477,9 +478,11 @@ __global__ void bnbwd_finalize_kernel(const double* __restrict__ sums, int C, do
         sdu += sums[(k * 3 + 2) * C + c];
     }
     if (q1) {
-        // quirk Q1: the zero border of the padded block input went through this BN; its upstream
-        // gradients sum to -(sum of interior dU) because the depthwise BN backward is mean-free.
-        const double gb = -sdu * (double)uda_act_gate(shift[c], act);
+        // quirk Q1: the zero border of the padded block input went through this BN.  Its upstream gradients sum to
+        // (sum over ALL padded positions) - (sum of interior dU); the total is 0 when the depthwise BatchNorm behind it is in
+        // training mode (its backward is mean-free) and is handed in as q1_total when that BatchNorm is frozen
+        // (= colsum(dy_dw) * sum of the 9 depthwise taps, every tap of every output lands inside the padded input).
+        const double gb = ((q1_total ? (double)q1_total[c] : 0.0) - sdu) * (double)uda_act_gate(shift[c], act);
         sg += gb;
         sgx += gb * (-(double)mean[c] * (double)invstd[c]);
     }
@@ -490,11 +493,11 @@ __global__ void bnbwd_finalize_kernel(const double* __restrict__ sums, int C, do
 }
 
 extern "C" int uda_bnbwd_finalize(const double* sums, int C, double count, int q1_border, int act, const float* shift,
-                                  const float* mean, const float* invstd, float* c1, float* c2, float* dgamma,
-                                  float* dbeta, void* stream) {
+                                  const float* mean, const float* invstd, const float* q1_total, float* c1, float* c2,
+                                  float* dgamma, float* dbeta, void* stream) {
     UDA_REQUIRE(sums && shift && mean && invstd && c1 && c2 && dgamma && dbeta && C > 0 && count > 0, "uda_bnbwd_finalize: bad args");
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3(uda_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, count,
-                       q1_border, act, shift, mean, invstd, c1, c2, dgamma, dbeta);
+                       q1_border, act, shift, mean, invstd, q1_total, c1, c2, dgamma, dbeta);
     UDA_LAUNCH_CHECK("bnbwd_finalize");
     return 0;
 }

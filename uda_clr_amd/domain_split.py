@@ -107,9 +107,9 @@ class DomainSplit:
         for h, n0, n1 in self._halves(y.N):
             self.K.bnbwd_reduce(_rows(dU, y.N, n0, n1), y.half(h), sums[h])
 
-    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
+    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta, q1_total=None):
         if not y.split:
-            return self.K.bnbwd_finalize(sums, y, c1, c2, dgamma, dbeta)
+            return self.K.bnbwd_finalize(sums, y, c1, c2, dgamma, dbeta, q1_total)
         for h in (0, 1):
             self.K.bnbwd_finalize(sums[h], y.half(h), c1[h], c2[h], dgamma[h], dbeta[h])
 

@@ -86,7 +86,7 @@ class _Arena:
 
 
 class _Ctx:
-    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt", "bnlog", "tn_repeat")
+    __slots__ = ("S", "N", "dims", "w_cache", "params", "x", "arena", "nbt", "bnlog", "tn_repeat", "need_grad")
 
     def __init__(self):
         self.S = {}
@@ -225,7 +225,16 @@ class GeneratorEngine:
             ctx.bnlog.append((prefix, rec))
             return rec
         self.K.bn_eval_coeffs(g, b, rm, rv, BN_EPS, scale, shift)
-        return None
+        if not ctx.need_grad:
+            return None
+        # frozen BatchNorm inside a training pass (DeepLab.freeze_bn, deeplabv3.py:43-50): the backward needs xhat against the
+        # running statistics; count = inf switches the batch-statistics terms off (uda_bnbwd_finalize)
+        istd = torch.rsqrt(rv + BN_EPS)
+        if mean is not None:             # callers that keep (mean, invstd) in their coefficient block (the ASPP's shared one)
+            mean.copy_(rm)
+            invstd.copy_(istd)
+            return BNRec(prefix, mean, invstd, float("inf"), q1, frozen=True)
+        return BNRec(prefix, rm, istd, float("inf"), q1, frozen=True)
 
     def _tn(self, ctx, prefix, stats, count, training, scale, shift, mean, invstd, q1, N):
         """TransNorm coefficients.  Training: scale / shift / mean / invstd are [2, C] (row h = domain half h), the
@@ -507,7 +516,12 @@ class GeneratorEngine:
                 K.dwconv_dgrad(dyd, self._w(ctx, pre + kd + ".weight", "dw"), stride, dil, N, Hi, Wi, dUe)
             del dUd, dyd, dyp
             if t != 1:
-                dye = self._bn_backward(ctx, G, e, dUe)
+                q1_total = None
+                if e.bn.frozen:
+                    # quirk Q1 with a frozen depthwise BN behind: the gradient summed over ALL padded positions of the block input
+                    # is colsum(dy_dw) * sum of the depthwise taps = scale_dw * dbeta_dw * sum_t w (engine docstring)
+                    q1_total = (d.scale * G[pre + kdb + ".bias"] * ctx.params[pre + kd + ".weight"].sum((1, 2, 3))).contiguous()
+                dye = self._bn_backward(ctx, G, e, dUe, q1_total=q1_total)
                 self._wgrad(ctx, G, pre + ".conv.0.weight", zin, dye, 1, 1)
                 d_zin = self._buf(x, zin.P, zin.C)
                 addend = d_z if r["use_res"] else (d_low if i == 4 else None)
@@ -524,7 +538,7 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, params: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
-                need_grad: bool, masks=None, repeat_prefix: bool = False):
+                need_grad: bool, masks=None, repeat_prefix: bool = False, bn_training: Optional[bool] = None):
         """``repeat_prefix`` (TransNorm only): run the deterministic part of the network (up to the ASPP output before its
         dropout and the decoder's low-level branch) as it comes out for the batch ``x.repeat(2, 1, 1, 1)`` - both TransNorm halves
         are x - without touching running statistics; returns (None, ctx) for ``mc_forward``."""
@@ -532,6 +546,13 @@ class GeneratorEngine:
         ctx = _Ctx()
         ctx.tn_repeat = bool(repeat_prefix and self.tn)
         ctx.params, ctx.x = params, x
+        ctx.need_grad = bool(need_grad)
+        # ``training`` drives the dropout layers; the BatchNorm layers follow ``bn_training`` (default: the same), which
+        # DeepLab.freeze_bn() turns off while the model keeps training (deeplabv3.py:43-50)
+        drop_tr = training
+        training = training if bn_training is None else bool(bn_training)
+        if self.tn and training != drop_tr:
+            raise NotImplementedError("frozen TransNorm layers inside a training pass are not built")
         S = ctx.S
         N, _, Hin, Win = x.shape
         if Hin % 16 or Win % 16:
@@ -574,7 +595,7 @@ class GeneratorEngine:
         y1 = self._empty(x, P16, 256)
         st = self._stats(ctx, 256, training)
         K.conv(catA, self._w(ctx, "aspp.conv1.weight", "ohwi"), 1, 1, y1, stats=st)
-        m, ms = self._mask(x, "aspp.dropout", P16, 256, N, H16, W16, training, masks)
+        m, ms = self._mask(x, "aspp.dropout", P16, 256, N, H16, W16, drop_tr, masks)
         fa = self._bn_act(ctx, "aspp.bn1", y1, N, H16, W16, st, P16, training, ACT_RELU, m, ms)
         feature = self._empty(x, P16, 256)
         K.bn_apply(fa, feature, None)
@@ -600,13 +621,13 @@ class GeneratorEngine:
         yb1 = self._empty(x, P4, 256)
         st = self._stats(ctx, 256, training)
         y0 = self._conv0(ctx, feature, xf, N, H16, W16, H4, W4, yb1, st)
-        m, ms = self._mask(x, "decoder.last_conv_boundary.3", P4, 256, N, H4, W4, training, masks)
+        m, ms = self._mask(x, "decoder.last_conv_boundary.3", P4, 256, N, H4, W4, drop_tr, masks)
         b1 = self._bn_act(ctx, "decoder.last_conv_boundary.1", yb1, N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
         yb2 = self._empty(x, P4, 256)
         st = self._stats(ctx, 256, training)
         K.conv(b1, self._w(ctx, "decoder.last_conv_boundary.4.weight", "ohwi"), 3, 1, yb2, stats=st)
-        m, ms = self._mask(x, "decoder.last_conv_boundary.7", P4, 256, N, H4, W4, training, masks)
+        m, ms = self._mask(x, "decoder.last_conv_boundary.7", P4, 256, N, H4, W4, drop_tr, masks)
         b2 = self._bn_act(ctx, "decoder.last_conv_boundary.5", yb2, N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
         K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1,
@@ -614,7 +635,7 @@ class GeneratorEngine:
         st = self._stats(ctx, 305, training)
         if training:
             K.colstats(xf[:, :305], st, **({"N": N} if self.tn else {}))
-        m, ms = self._mask(x, "decoder.last_conv.2", P4, 305, N, H4, W4, training, masks)
+        m, ms = self._mask(x, "decoder.last_conv.2", P4, 305, N, H4, W4, drop_tr, masks)
         sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
         x1b = self._buf(x, P4, 2)
@@ -731,12 +752,12 @@ class GeneratorEngine:
         return out
 
     # ------------------------------------------------------------------ backward pieces
-    def _bn_backward(self, ctx, G, y: Act, dU, out=None, addend=None, keys=None):
+    def _bn_backward(self, ctx, G, y: Act, dU, out=None, addend=None, keys=None, q1_total=None):
         """dU: gradient w.r.t. the activated values of ``y``.  Writes the gradient w.r.t. the raw
         tensor y.x into ``out`` (default: in place over dU) and the BN parameter gradients into G."""
         K = self.K
         if y.bn is None:
-            raise NotImplementedError("backward through frozen (eval-mode) BatchNorm is not built yet")
+            raise RuntimeError("this activation's BatchNorm kept no backward record (forward ran without gradient bookkeeping)")
         C = y.C
         if y.split:
             # TransNorm: z = (xhat*gamma + beta) * gain per domain half, gain detached (batchnorm.py:495).  The per-half
@@ -747,7 +768,7 @@ class GeneratorEngine:
             sums = ctx.arena.take(3, C)
             cg = self._empty(dU, 4, C)
         K.bnbwd_reduce(dU, y, sums)
-        K.bnbwd_finalize(sums, y, cg[0], cg[1], cg[2], cg[3])
+        K.bnbwd_finalize(sums, y, cg[0], cg[1], cg[2], cg[3], **({} if q1_total is None else {"q1_total": q1_total}))
         out = dU if out is None else out
         K.bnbwd_apply(dU, y, cg[0], cg[1], out, addend)
         if y.split:
@@ -870,7 +891,7 @@ class GeneratorEngine:
             gain4 = torch.cat([r.gain for r in A["brecs"]])
             gaing = A["grec"].gain
         else:
-            cnt4, cntg, gain4, gaing = float(P16), float(N), None, None
+            cnt4, cntg, gain4, gaing = A["brecs"][0].count, A["grec"].count, None, None      # P16 and N, or inf when frozen
         c4 = Act(cat[:, :1024], N, H16, W16, coef[0][..., w4], coef[1][..., w4], ACT_RELU, None, 1.0,
                  BNRec("aspp", coef[2][..., w4], coef[3][..., w4], cnt4, False, gain4), split=catA.split)
         keys = [("aspp.aspp%d.bn" % j, slice(256 * (j - 1), 256 * j)) for j in (1, 2, 3, 4)]

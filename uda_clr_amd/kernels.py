@@ -80,7 +80,7 @@ SYMBOLS = {
     "uda_bn_apply": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
     "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P]),
     "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P]),
-    "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "uda_bnbwd_apply": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "uda_upsample_fwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
     "uda_upsample_bwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
@@ -528,9 +528,11 @@ class HipKernels:
         self._ck(self.lib.uda_bnbwd_reduce(d, ldu, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
                                            sums.data_ptr(), self._stream()))
 
-    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta):
+    def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta, q1_total=None):
+        if q1_total is not None:
+            assert q1_total.is_contiguous() and q1_total.numel() == y.C and q1_total.dtype == torch.float32
         self._ck(self.lib.uda_bnbwd_finalize(sums.data_ptr(), y.C, float(y.bn.count), int(y.bn.q1_border), y.act,
-                                             y.shift.data_ptr(), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
+                                             y.shift.data_ptr(), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(), _ptr(q1_total),
                                              c1.data_ptr(), c2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                              self._stream()))
 

@@ -33,9 +33,10 @@ class _GeneratorFn(torch.autograd.Function):
         engine = module._engine_for(x)
         params = module._flat_state()
         masks, module._next_masks = module._next_masks, None
-        outs, ectx = engine.forward(params, x, module._bn_training(), need_grad, masks)
+        bn_tr = module._bn_training()
+        outs, ectx = engine.forward(params, x, module.training, need_grad, masks, bn_training=bn_tr)
         ctx.engine, ctx.ectx, ctx.keys, ctx.module = engine, ectx, keys, module
-        if ectx is not None and module.training:
+        if ectx is not None and module.training and bn_tr:      # (the MC fast path replays batch statistics: training-mode BN only)
             module._remember(x, ectx)
         return outs
 
@@ -178,9 +179,9 @@ class DeepLab(Holder):
         if len(flags) != 1:
             raise NotImplementedError("mixed train/eval BatchNorm layers are not built")
         flag = flags.pop()
-        if flag != self.training:
-            raise NotImplementedError("freeze_bn while training (eval-mode BN backward) is not built yet")
-        return flag
+        if flag and not self.training:
+            raise NotImplementedError("training-mode BatchNorm layers inside an eval-mode model are not built")
+        return flag          # False while self.training: freeze_bn() (deeplabv3.py:43-50) - frozen statistics, live dropout
 
     def _engine_for(self, x):
         if self._engine_override is not None:

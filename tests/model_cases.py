@@ -184,7 +184,7 @@ def golden_parity(dev, tag):
     oracle-recovered dropout masks of the reference's own draw."""
     z = np.load(os.path.join(GOLDEN, "forward_%s.npz" % tag))
     B, S = int(z["B"]), int(z["S"])
-    m = seeded_model(backbone="resnet" if tag.startswith("resnet") else "mobilenet", transnorm=tag.startswith("tn"))
+    m = seeded_model(backbone="resnet" if tag.startswith("resnet") else "mobilenet", transnorm="tn" in tag.split("_"))
     torch.manual_seed(int(z["input_seed"]))
     x = torch.randn(B, 3, S, S)
     errs = {}
@@ -195,7 +195,7 @@ def golden_parity(dev, tag):
     # layer's output (alpha = 1): rounding differences between two fp32 evaluations grow ~2.3x per block (0.1 at the outputs
     # for ANY other summation order than the reference's own), so the eval half of the tn fixture pins the oracle only;
     # the eval path itself is checked on calibrated statistics (eval_parity(transnorm=True))
-    for n, t in zip(NAMES, [] if tag.startswith("tn") else out):
+    for n, t in zip(NAMES, [] if "tn" in tag.split("_") else out):
         d = t.double().cpu()
         f = d.reshape(-1)
         idx = torch.linspace(0, f.numel() - 1, 97).long()

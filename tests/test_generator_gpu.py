@@ -326,3 +326,21 @@ def test_frozen_batchnorm_training_matches_oracle_and_reference_fixture():
     gn = np.array([live[str(k)].grad.double().norm().item() for k in z["train.grad_keys"]])
     rel_gn = np.abs(gn - z["train.grad_norm"]) / np.maximum(z["train.grad_norm"], 1e-12)
     assert rel_gn.max() < 1e-2 and np.median(rel_gn) < 5e-4, (rel_gn.max(), np.median(rel_gn))
+
+
+def test_resnet_transnorm_on_the_hip_kernels():
+    """DeepLab(backbone='resnet', sync_bn=False) (deeplabv3.py:17-23): per-domain-half launches of the ResNet-101 sequence on
+    the HIP kernels against the fp64 oracle (halves of 2 + 2 images), and against the fixture the reference's own model wrote
+    (forward_resnet_tn_128.npz: training loss, outputs, running statistics; gradient norms in the median)."""
+    fwd, grads, stats, fwd64 = model_cases.train_parity(DEV, B=4, S=64, backbone="resnet", transnorm=True)
+    for n, (e, floor) in fwd64.items():
+        assert e < 3.0 * floor + 2e-4, (n, e, floor)
+    assert stats < 5e-3
+    bad, gmean = model_cases.grads_ok(grads)
+    print("gradient noise vs the fp32 oracle's: geometric mean %.3f over %d tensors" % (gmean, len(grads)))
+    assert not bad, list(bad.items())[:10]
+    assert gmean < 4.0, gmean
+    errs = model_cases.golden_parity(DEV, "resnet_tn_128")
+    tol = {"train.grad_norm.conv": 0.2, "train.grad_norm.median": 0.2, "train.bn_sum": 5e-3}
+    for k, v in errs.items():
+        assert v < tol.get(k, 5e-3), (k, v)

@@ -215,3 +215,45 @@ def test_mc_fast_path_under_transnorm_equals_plain_stochastic_forwards():
         elif leaf == "num_batches_tracked":
             assert int(live[k]) == int(v) == 1 + passes, k
     assert n_buf == 4 * 61
+
+
+# ---------------------------------------------------------------- TransNorm on the ResNet-101 backbone (deeplabv3.py:17-23 allows it)
+def test_resnet_transnorm_state_dict_and_oracle_against_reference_fixture(golden_dir):
+    """DeepLab(backbone='resnet', sync_bn=False): state-dict keys / shapes / seeded init of the reference's own model
+    (manifest_resnet_tn.json), and the oracle's training forward + backward on it against forward_resnet_tn_128.npz (B = 4)."""
+    man = json.load(open(os.path.join(golden_dir, "manifest_resnet_tn.json")))
+    torch.manual_seed(man["seed"])
+    sd0 = DeepLab(num_classes=2, backbone="resnet", output_stride=16, sync_bn=False).state_dict()
+    assert len(sd0) == man["n_state_keys"]
+    for e, (k, v) in zip(man["entries"], sd0.items()):
+        assert e["key"] == k and e["shape"] == list(v.shape), (e["key"], k)
+        assert abs(float(v.double().sum()) - e["sum"]) <= 1e-6 * max(1.0, abs(e["sum"])), k
+    z = np.load(os.path.join(golden_dir, "forward_resnet_tn_128.npz"))
+    B, S = int(z["B"]), int(z["S"])
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    osd = deeplab_ref.canonical_state(sd0, requires_grad=True)
+    torch.manual_seed(int(z["dropout_seed"]))
+    out = deeplab_ref.deeplab_forward(osd, x, training=True)
+    loss = step_ref.seg_loss(out[0], out[1], tmap, tbd)
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-6
+    gn = np.array([osd[k].grad.double().norm().item() for k in z["train.grad_keys"]])
+    np.testing.assert_allclose(gn, z["train.grad_norm"], rtol=1e-4)
+    bs = np.array([osd[k].double().sum().item() for k in z["train.bn_keys"]])
+    np.testing.assert_allclose(bs, z["train.bn_sum"], rtol=1e-5, atol=1e-6)
+
+
+def test_resnet_transnorm_engine_matches_oracle():
+    """The engine's per-domain-half execution on the ResNet-101 launch sequence (7x7 stem, max-pool, bottleneck tails run per
+    half): halves of 2 + 2 images at 64^2.  104 TransNorm layers over 2 x 2 x 2 samples in the deepest maps: the fp32 oracle is
+    itself 1.4e-3 from its fp64 run, outputs are held to 3x that distance."""
+    fwd, grads, stats, fwd64 = model_cases.train_parity(torch.device("cpu"), B=4, S=64, backbone="resnet", transnorm=True,
+                                                        engine=GeneratorEngine(SpecKernels(), backbone="resnet", transnorm=True))
+    for n, (e, floor) in fwd64.items():
+        assert e < 3.0 * floor + 2e-4, (n, e, floor)
+    assert stats < 5e-3
+    bad, gmean = model_cases.grads_ok(grads)
+    assert not bad, list(bad.items())[:10]
+    assert gmean < 1.5, gmean

@@ -71,6 +71,26 @@ class DomainSplit:
         for h, n0, n1 in self._halves(N):
             self.K.stem_fwd(x[n0:n1], w, _rows(out, N, n0, n1), stats[h])
 
+    def stem7_fwd(self, x, w, out, stats=None):
+        if stats is None or stats.dim() == 3:
+            return self.K.stem7_fwd(x, w, out, stats)
+        N = x.shape[0]
+        for h, n0, n1 in self._halves(N):
+            self.K.stem7_fwd(x[n0:n1], w, _rows(out, N, n0, n1), stats[h])
+
+    def maxpool_fwd(self, src: Act, out, idx):
+        if not src.split:
+            return self.K.maxpool_fwd(src, out, idx)
+        for h, n0, n1 in self._halves(src.N):
+            self.K.maxpool_fwd(src.half(h), _rows(out, src.N, n0, n1), _rows(idx, src.N, n0, n1))
+
+    def bn_add_relu(self, a: Act, b: Act, out):
+        if not a.split and not b.split:
+            return self.K.bn_add_relu(a, b, out)
+        N = a.N
+        for h, n0, n1 in self._halves(N):
+            self.K.bn_add_relu(self._sub(a, h, n0, n1), self._sub(b, h, n0, n1), _rows(out, N, n0, n1))
+
     def colstats(self, x, stats, N=None):
         if stats.dim() == 3:
             return self.K.colstats(x, stats)

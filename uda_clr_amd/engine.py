@@ -127,8 +127,6 @@ class GeneratorEngine:
         # TransNorm (--use_TN, networks/sync_batchnorm/batchnorm.py:436-520): training batches are normalised per
         # domain half; the same launch sequence runs through DomainSplit, which issues per-half launches
         self.tn = bool(transnorm)
-        if self.tn and backbone != "mobilenet":
-            raise NotImplementedError("TransNorm is built for the mobilenet backbone")
         self.K = DomainSplit(kernels) if self.tn else kernels
         self.os = output_stride
         self.backbone = backbone
@@ -403,7 +401,7 @@ class GeneratorEngine:
                 K.conv(a1, self._w(ctx, pre + ".conv2.weight", "ohwi"), 3, dil, yfull)
                 K.rows_stride(yfull, N, H, W, stride, y2)
                 if training:
-                    K.colstats(y2, st)
+                    K.colstats(y2, st, **({"N": N} if self.tn else {}))
                 del yfull
             a2 = self._bn_act(ctx, pre + ".bn2", y2, N, Ho, Wo, st, Po, training, ACT_RELU)
             y3 = self._buf(x, Po, 4 * planes)

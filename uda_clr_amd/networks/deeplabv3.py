@@ -58,8 +58,6 @@ class DeepLab(Holder):
             raise NotImplementedError("the fused heads are built for num_classes=2 (cup, disc)")
         # deeplabv3.py:17-23: sync_bn=True is plain nn.BatchNorm2d, sync_bn=False (--use_TN) is TransNorm
         self.transnorm = not sync_bn
-        if self.transnorm and backbone != 'mobilenet':
-            raise NotImplementedError("TransNorm is built for the mobilenet backbone (the only one train_use_fix_initial.py builds)")
         BatchNorm = TransNorm2d if self.transnorm else nn.BatchNorm2d
         self.output_stride = output_stride
         self.backbone_name = backbone

@@ -32,3 +32,41 @@ def test_kernel_matches_spec_on_the_other_matrix_instructions(name, fn):
     finally:
         K.mfma = keep
     assert err <= tol, "%s (mfma mode %d): rel err %.3e > %.1e" % (name, 1 - keep, err, tol)
+
+
+def test_operands_beyond_the_32_bit_offsets_run_as_image_groups():
+    """The conv / weight-gradient kernels take at most 2^29 elements per operand; HipKernels splits larger batches into groups
+    of whole images.  With the limit lowered so that a 6-image batch needs 3 groups, results equal the single launch (outputs
+    bit for bit: same per-row arithmetic; statistics and weight gradients up to summation order)."""
+    import kernel_cases
+    from kernel_cases import make_src, act_to, gen, padded, to_dev, rel
+    dev = torch.device("cuda:0")
+    K = kernel_cases.hip()
+    g = gen(5)
+    N, H, W, Cin, Cout = 6, 24, 20, 64, 160
+    src = act_to(make_src(N, H, W, Cin, g, True, 1, True), dev)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev) / 24.0
+    wl = K.relayout_ohwi(w)
+    P = N * H * W
+    dy = torch.randn(P, Cout, generator=g).to(dev)
+    res = {}
+    for mode in (K.MFMA_F32, K.MFMA_BF16X3):
+        keep_mode, K.mfma = K.mfma, mode
+        for tag, lim in (("one", 1 << 29), ("groups", (2 * H * W + 300) * max(src.x.stride(0), Cout))):
+            keep = K.ELEM_LIMIT
+            type(K).ELEM_LIMIT = lim
+            try:
+                if tag == "groups":
+                    assert len(K._image_groups(N, H * W, max(src.x.stride(0), Cout), Cin if mode else 0)) == 3
+                out = torch.empty(P, Cout, device=dev)
+                st = torch.zeros(16, 2, Cout, dtype=torch.float64, device=dev)
+                K.conv(src, wl, 3, 1, out, stats=st)
+                dw = torch.empty(Cout, Cin, 3, 3, device=dev)
+                K.conv_wgrad(src, dy, 3, 1, dw)
+                res[(mode, tag)] = (out, st.sum(0), dw)
+            finally:
+                type(K).ELEM_LIMIT = keep
+        K.mfma = keep_mode
+        a, b = res[(mode, "one")], res[(mode, "groups")]
+        assert torch.equal(a[0], b[0])
+        assert rel(b[1], a[1]) < 1e-12 and rel(b[2], a[2]) < 1e-5

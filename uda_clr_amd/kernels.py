@@ -225,7 +225,39 @@ class HipKernels:
         return out
 
     # ------------------------------------------------------------------ dense conv
+    # The conv / weight-gradient kernels address their operands with 32-bit offsets: rows * row stride of one operand must stay
+    # below 2^29 elements (fp32) resp. 2^27 sixteen-byte units of the packed bf16x3 operand.  Larger batches are run as groups
+    # of whole images (a convolution never crosses an image; statistics are ADDED into, weight gradients summed).
+    ELEM_LIMIT = 1 << 29
+
+    def _image_groups(self, N, rows_per_image, widest_ld, x3_channels=0):
+        """None when one launch can take the whole operand, else [(n0, n1)] image ranges that can."""
+        lim_rows = self.ELEM_LIMIT // max(int(widest_ld), 1) - 256
+        if x3_channels:
+            lim_rows = min(lim_rows, (self.ELEM_LIMIT // 4) // (((x3_channels + 15) // 16) * 6) - 256)
+        if N * rows_per_image <= lim_rows:
+            return None
+        g = lim_rows // rows_per_image
+        if g < 1:
+            raise UdaError("one image (%d pixels x %d floats per row) exceeds the 32-bit offsets of the conv kernels" % (rows_per_image, widest_ld))
+        return [(n0, min(N, n0 + g)) for n0 in range(0, N, g)]
+
+    @staticmethod
+    def _act_rows(a: Act, n0, n1):
+        ppi = a.P // a.N
+        r = slice(n0 * ppi, n1 * ppi)
+        return Act(a.x[r], n1 - n0, a.H, a.W, a.scale, a.shift, a.act, None if a.mask is None else a.mask[r], a.mask_scale, a.bn, a.meta)
+
     def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
+        groups = self._image_groups(src.N, src.P // src.N, max(src.x.stride(0), out.stride(0), 0 if addend is None else addend.stride(0),
+                                                               0 if src.mask is None else src.mask.stride(0) // 4),
+                                    src.C if self.mfma != self.MFMA_F32 else 0)
+        if groups is not None:
+            ppi = src.P // src.N
+            for n0, n1 in groups:
+                r = slice(n0 * ppi, n1 * ppi)
+                self.conv(self._act_rows(src, n0, n1), w, ksize, dil, out[r], bias, None if addend is None else addend[r], stats, origin)
+            return
         a = UdaConvArgs()
         a.origin = origin
         a.src = self._src(src)
@@ -282,6 +314,15 @@ class HipKernels:
         return self.x3_pack(s, rows, klen, w.device)
 
     def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
+        groups = self._image_groups(src.N, src.P // src.N, max(src.x.stride(0), dy.stride(0), 0 if src.mask is None else src.mask.stride(0) // 4))
+        if groups is not None:
+            ppi = src.P // src.N
+            tmp = torch.empty_like(dw)
+            for i, (n0, n1) in enumerate(groups):
+                self.conv_wgrad(self._act_rows(src, n0, n1), dy[n0 * ppi:n1 * ppi], ksize, dil, dw if i == 0 else tmp, origin)
+                if i:
+                    dw.add_(tmp)
+            return
         a = UdaWgradArgs()
         a.origin = origin
         a.src = self._src(src)

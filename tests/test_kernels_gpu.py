@@ -69,4 +69,4 @@ def test_operands_beyond_the_32_bit_offsets_run_as_image_groups():
         K.mfma = keep_mode
         a, b = res[(mode, "one")], res[(mode, "groups")]
         assert torch.equal(a[0], b[0])
-        assert rel(b[1], a[1]) < 1e-12 and rel(b[2], a[2]) < 1e-5
+        assert rel(b[1], a[1]) < 1e-6 and rel(b[2], a[2]) < 1e-5      # per-tile fp32 partials of the statistics shift with the tile origin

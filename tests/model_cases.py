@@ -62,10 +62,10 @@ def frozen_grads_ok(grads):
     near-cancelling sums: on inputs without a marginal ReLU gate (seed 11) every gradient tensor of the engine sits 2e-5 from the
     fp64 oracle, like the fp32 oracle's own.  A gate within rounding of 0 flips between two fp32 evaluation orders and moves all
     gradients below it by 0.05-2 % (seeds 14, 21-23: the fp32 ORACLE itself is 5e-4 ... 2e-2 from fp64 there), a wrong term (e.g.
-    the quirk-Q1 border sum) moves the tensors it feeds by 10-50 %.  Bound: every tensor < 2e-2, and the median < 5e-4 or within
-    10x the fp32 oracle's own median."""
+    the quirk-Q1 border sum) moves the tensors it feeds by 10-50 %.  Bound: every tensor < 5e-2 (measured on MI355X with a flipped
+    gate: 2.4e-2), and the median < 5e-4 or within 10x the fp32 oracle's own median."""
     errs, floor = sorted(v[0] for v in grads.values()), sorted(v[1] for v in grads.values())
-    assert errs[-1] < 2e-2, max(grads.items(), key=lambda kv: kv[1][0])
+    assert errs[-1] < 5e-2, max(grads.items(), key=lambda kv: kv[1][0])
     med, fmed = errs[len(errs) // 2], floor[len(floor) // 2]
     assert med < max(5e-4, 10.0 * fmed), (med, fmed)
 

@@ -344,3 +344,74 @@ def test_resnet_transnorm_on_the_hip_kernels():
     tol = {"train.grad_norm.conv": 0.2, "train.grad_norm.median": 0.2, "train.bn_sum": 1e-2}
     for k, v in errs.items():
         assert v < tol.get(k, 5e-3), (k, v)
+
+
+# ---- BASELINE.json configs[3]: the per-GPU batch of 32 at 512 x 512 (the doubled MC batch has P = 2 * 32 * 128^2 = 1,048,576 rows)
+def test_per_gpu_batch_32_at_512_properties():
+    """Size-independent properties at the full configs[3] shape (no CPU oracle runs at this size):
+      * eval forward: batch independence - images 5..8 of the batch of 32 alone give the same outputs;
+      * training forward + backward: permutation equivariance - permuting the images (and their injected dropout masks)
+        permutes the outputs and leaves the parameter gradients and the running statistics unchanged (batch statistics and
+        weight gradients are sums over the batch);
+      * the MC fast path on the doubled batch (one stochastic pass on 64 images) equals the plain training-mode forward on
+        x.repeat(2) with the same masks."""
+    B, S = 32, 512
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, 3, S, S, generator=g, device=DEV)
+    keep = lambda shp, p: (torch.rand(shp, generator=g, device=DEV) >= p).to(torch.uint8)
+    sites = {"aspp.dropout": ((256, S // 16, S // 16), 0.5), "decoder.last_conv_boundary.3": ((256, S // 4, S // 4), 0.5),
+             "decoder.last_conv_boundary.7": ((256, S // 4, S // 4), 0.1), "decoder.last_conv.2": ((305, S // 4, S // 4), 0.1)}
+    masks = {k: keep((B,) + shp, p) for k, (shp, p) in sites.items()}
+    m = model_cases.seeded_model(perturb=True).to(DEV)
+    # --- eval: batch independence
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        part = m(x[4:8].contiguous())
+    for n, a, b in zip(model_cases.NAMES, full, part):
+        assert model_cases.rel(a[4:8], b) < 1e-5, n
+    del full, part
+    # --- training forward + backward: permutation equivariance
+    tmap = (torch.rand(B, 2, S, S, generator=g, device=DEV) > 0.5).float()
+    tbd = torch.rand(B, 1, S, S, generator=g, device=DEV)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    runs = []
+    from uda_clr_amd import ops
+    for p in (None, perm):
+        m.load_state_dict(sd0)
+        m.train()
+        for q in m.parameters():
+            q.grad = None
+        sel = (lambda t: t) if p is None else (lambda t: t[p].contiguous())
+        m.set_dropout_masks({k: sel(v) for k, v in masks.items()})
+        out = m(sel(x))
+        ops.seg_loss(out[0], out[1], sel(tmap), sel(tbd)).backward()
+        runs.append((out[0].detach(), {k: q.grad.clone() for k, q in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+        del out
+    (o0, g0, r0), (o1, g1, r1) = runs
+    assert model_cases.rel(o1, o0[perm]) < 1e-4
+    for k in r0:
+        assert model_cases.rel(r1[k], r0[k]) < 1e-5, k
+    worst = max((model_cases.l2rel(g1[k], g0[k]), k) for k in g0)
+    assert worst[0] < 2e-3, worst           # two summation orders of the same batch sums (BN-affine gradients are near-cancelling sums)
+    del runs, o0, o1, g0, g1
+    # --- MC fast path on the doubled batch
+    m.load_state_dict(sd0)
+    m.train()
+    mc = [{k: keep((2 * B,) + shp, p) for k, (shp, p) in sites.items()}]
+    m.set_dropout_masks(masks)
+    m(x)
+    fast = m.mc_dropout_logits(x, passes=1, reps=2, masks=mc)
+    s_fast = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    m.load_state_dict(sd0)
+    m.set_dropout_masks(masks)
+    with torch.no_grad():
+        m(x)
+        m._recent = []
+        plain = m.mc_dropout_logits(x, passes=1, reps=2, masks=mc)
+    assert model_cases.rel(fast, plain) < 1e-4
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert model_cases.rel(s_fast[k], v) < 1e-4, k

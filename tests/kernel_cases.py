@@ -224,7 +224,7 @@ def case_transnorm(C, n0=300, n1=500, seed=9):
     return run
 
 
-def case_bn(P, C, q1=False, mask=False, training=True, seed=5):
+def case_bn(P, C, q1=False, mask=False, training=True, seed=5, frozen=False):
     def run(dev):
         g = gen(seed)
         K = hip()
@@ -265,7 +265,12 @@ def case_bn(P, C, q1=False, mask=False, training=True, seed=5):
             o_h = to_dev(padded(P, C, g), dev)
             K.bn_apply(act_to(src, dev), o_h, to_dev(res, dev))
             errs.append(rel(o_h, o_r))
-        if training:
+        if training or frozen:
+            q1t = None
+            if frozen:       # eval-mode BN inside a training pass (freeze_bn): xhat against the running statistics, count = inf,
+                cr[2], cr[3] = rm, torch.rsqrt(rv + 1e-5)      # and the quirk-Q1 total handed in
+                cnt = float("inf")
+                q1t = torch.randn(C, generator=g) if q1 else None
             mb = None
             if mask:
                 mbuf = torch.zeros(P, round4(C), dtype=torch.uint8)
@@ -282,9 +287,10 @@ def case_bn(P, C, q1=False, mask=False, training=True, seed=5):
             K.bnbwd_reduce(dUh, yh, s_h)
             errs.append(rel(s_h.sum(0), s_r.sum(0)))
             gr, gh = torch.empty(4, C), torch.empty(4, C, device=dev)
-            SPEC.bnbwd_finalize(s_r, y, gr[0], gr[1], gr[2], gr[3])
-            K.bnbwd_finalize(s_h, yh, gh[0], gh[1], gh[2], gh[3])
-            errs.append(rel(gh, gr))
+            SPEC.bnbwd_finalize(s_r, y, gr[0], gr[1], gr[2], gr[3], q1_total=q1t)
+            K.bnbwd_finalize(s_h, yh, gh[0], gh[1], gh[2], gh[3], q1_total=None if q1t is None else q1t.to(dev))
+            errs.append(rel(gh[2:], gr[2:]))
+            errs.append(float((gh[:2].cpu() - gr[:2]).abs().max()) if frozen else rel(gh[:2], gr[:2]))     # frozen: c1 = c2 = 0 exactly
             ad = padded(P, C, g)
             o_r = padded(P, C, g)
             SPEC.bnbwd_apply(dU, y, gr[0], gr[1], o_r, ad)
@@ -436,6 +442,8 @@ CASES = [
     ("bn C=96 q1", case_bn(1500, 96, q1=True)),
     ("bn C=256 mask", case_bn(700, 256, mask=True)),
     ("bn C=305 mask (C%4!=0)", case_bn(600, 305, mask=True)),
+    ("bn frozen (eval-mode backward) C=96 q1 total", case_bn(1500, 96, q1=True, training=False, frozen=True)),
+    ("bn frozen (eval-mode backward) C=256 mask", case_bn(700, 256, mask=True, training=False, frozen=True)),
     ("transnorm gain / eval coefficients C=305", case_transnorm(305)),
     ("transnorm gain / eval coefficients C=1280 (> one pass of the workgroup)", case_transnorm(1280, 40, 24)),
     ("bn C=1024 (concat)", case_bn(300, 1024)),

@@ -115,8 +115,11 @@ typedef struct uda_wgrad_args {
     uint64_t workspace_bytes;
     int32_t mfma;          /* UDA_MFMA_*, as in uda_conv_args_t */
     int32_t _pad3;
+    const void* x3_src;    /* UDA_MFMA_BF16X3, when uda_conv_wgrad_uses_x3(a): src packed by uda_x3_pack (the forward conv's packed form) ... */
+    const void* x3_dy;     /* ... and dy ([P] rows of Cout values) packed by uda_x3_pack */
 } uda_wgrad_args_t;
 uint64_t uda_conv_wgrad_workspace_bytes(int64_t P, int Cout, int Cin, int ksize);
+int uda_conv_wgrad_uses_x3(const uda_wgrad_args_t* a);
 int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream);
 
 /* ---- depthwise 3x3 (mobilenet.py:39,53): stride 1|2, dilation 1|2, "pad 0 on a padded input".

@@ -60,3 +60,37 @@ for name, N, H, W, Cin, Cout, k, dil, lazy, mask in cases:
         line += " | %s %7.3f ms %6.1f TF err64 %.2e" % (tag, ms, flops / ms / 1e9, e)
     line += " | speedup %.2fx" % (res["f32"][0] / res["bf16x3"][0])
     print(line, flush=True)
+
+# ---------------------------------------------------------------- weight gradients (packed operands exist already in a training step:
+# timed with the packs cached, and once with dy's pack included)
+wcases = [("wgrad conv4 3x3 256->256 B=16", 16, 128, 128, 256, 256, 3, 1, True, True),
+          ("wgrad conv3 3x3 304->256 B=16", 16, 128, 128, 304, 256, 3, 1, False, False),
+          ("wgrad ASPP d=6 320->256 B=16", 16, 32, 32, 320, 256, 3, 6, True, False),
+          ("wgrad disc L2 2x2 256->128 B=16", 16, 131, 131, 256, 128, 2, 1, False, False),
+          ("wgrad disc L3 2x2 512->256 B=16", 16, 67, 67, 512, 256, 2, 1, False, False),
+          ("wgrad disc L4 2x2 1024->512 B=16", 16, 35, 35, 1024, 512, 2, 1, False, False)]
+if os.environ.get("X3_ONLY"):
+    wcases = [c for c in wcases if os.environ["X3_ONLY"] in c[0]]
+for name, N, H, W, Cin, Cout, k, dil, lazy, mask in wcases:
+    g = gen(1)
+    src = make_src(N, H, W, Cin, g, lazy, ACT_RELU, mask)
+    P = N * H * W
+    dy = torch.randn(P, Cout, generator=g).to(dev)
+    sh = act_to(src, dev)
+    dw = torch.empty(Cout, Cin, k, k, device=dev)
+    flops = 2.0 * P * Cout * Cin * k * k
+    res = {}
+    for mode, tag in ((K.MFMA_F32, "f32"), (K.MFMA_BF16X3, "bf16x3")):
+        K.mfma = mode
+        ms = timeit(lambda: K.conv_wgrad(sh, dy, k, dil, dw, origin=0))
+        res[tag] = (ms, dw.clone())
+
+    def with_pack():
+        if hasattr(dy, "_x3"):
+            del dy._x3
+        K.conv_wgrad(sh, dy, k, dil, dw, origin=0)
+    ms_pack = timeit(with_pack)
+    e = ((res["bf16x3"][1].double() - res["f32"][1].double()).norm() / res["f32"][1].double().norm()).item()
+    print("%-36s %6.1f GFLOP | f32 %7.3f ms %6.1f TF | bf16x3 %7.3f ms %6.1f TF (%.3f ms with the dy pack) | speedup %.2fx | rel diff %.1e" % (
+        name, flops / 1e9, res["f32"][0], flops / res["f32"][0] / 1e9, res["bf16x3"][0], flops / res["bf16x3"][0] / 1e9, ms_pack,
+        res["f32"][0] / res["bf16x3"][0], e), flush=True)

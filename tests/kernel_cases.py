@@ -783,6 +783,16 @@ CASES += [
     ("wgrad2x2 o0 64->256 P=131841 (256x256 tiles)", case_wgrad(1, 363, 363, 64, 256, 2, 1, lazy=False)),
 ]
 
+# weight gradients the bf16x3 mode routes to its own kernel (Cin % 16 == 0, Cout >= 96, k >= 2, P >= 4096; transposed LDS reads)
+CASES += [
+    ("wgrad3x3 256->256 P=4608 mask (x3 128 tiles)", case_wgrad(2, 48, 48, 256, 256, 3, 1, mask=True)),
+    ("wgrad3x3 304->256 P=8192 (x3 128 tiles)", case_wgrad(2, 64, 64, 304, 256, 3, 1, lazy=False)),
+    ("wgrad3x3 320->256 dil12 P=4608 (x3)", case_wgrad(2, 48, 48, 320, 256, 3, 12)),
+    ("wgrad3x3 48->100 P=4700 ragged (x3)", case_wgrad(2, 50, 47, 48, 100, 3, 1)),
+    ("wgrad2x2 o0 256->128 P=8978 (x3)", case_wgrad(2, 67, 67, 256, 128, 2, 1, lazy=False, origin=0)),
+    ("wgrad2x2 o0 64->200 P=70225 (x3 256 tiles, ragged)", case_wgrad(1, 265, 265, 64, 200, 2, 1, lazy=False, origin=0)),
+]
+
 
 # ---------------------------------------------------------------- input pipeline tail: bit-exact against scipy
 def _fundus_like(B, H, W, g):

@@ -730,6 +730,14 @@ extern "C" uint64_t uda_conv_wgrad_workspace_bytes(int64_t P, int Cout, int Cin,
     return (uint64_t)p.S * Cout * ksize * ksize * Kc * sizeof(float);
 }
 
+extern "C" int uda_conv_wgrad_uses_x3(const uda_wgrad_args_t* a) {
+    if (!a || a->mfma != UDA_MFMA_BF16X3 || a->ksize < 1 || a->ksize > 3) return 0;
+    const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
+    const WgradPlan p = wgrad_plan(P, a->Cout, a->src.C, a->ksize);
+    const bool wide = p.bm == 256 || (p.bm == 128 && p.bn == 128);
+    return wide && wgrad_x3_eligible(a->src.C, a->Cout, a->ksize, P) ? 1 : 0;
+}
+
 extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(a != nullptr, "uda_conv_wgrad: null args");
@@ -758,7 +766,9 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     k.chunks_per_split = p.cps;
     k.nchunks = p.nchunks;
     dim3 grid(p.nCot * p.nJt, p.S);
-    if (p.bm == 256) { if (int e = launch_wgrad_ws(k, p.S, true, st)) return e; }
+    int S_used = p.S;
+    if (uda_conv_wgrad_uses_x3(a)) { if (int e = launch_wgrad_x3(k, P, p.S, a->x3_src, a->x3_dy, st, S_used)) return e; }
+    else if (p.bm == 256) { if (int e = launch_wgrad_ws(k, p.S, true, st)) return e; }
     else if (p.bm == 128 && p.bn == 128) { if (int e = launch_wgrad_ws(k, p.S, false, st)) return e; }
     else if (p.bm == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, k);
     else if (p.bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1, 4, 1>), grid, dim3(256), 0, st, k);
@@ -767,7 +777,7 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     const int T = a->ksize * a->ksize;
     const int64_t total = (int64_t)a->Cout * T * a->src.C;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(uda_cdiv(total, 32) > 4096 ? 4096 : uda_cdiv(total, 32)), dim3(256), 0, st,
-                       k.slab, p.S, a->Cout, a->src.C, T, k.Kc, a->dw);
+                       k.slab, S_used, a->Cout, a->src.C, T, k.Kc, a->dw);
     UDA_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }

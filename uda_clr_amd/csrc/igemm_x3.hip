@@ -421,3 +421,229 @@ int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w
     if (mid) return launch_x3<1, 4, 128>(x, P, st);
     return launch_x3<1, 2, 128>(x, P, st);
 }
+
+// ==========================================================================================================================
+// Weight gradient on the bf16 pipe:  dw[co][j] = sum_p dy[p][co] * u[p + off_t][ci],  j = (t, ci): contraction over PIXELS.
+// Both operands are packed pixel-major ([pixel][channel block][3][16]), i.e. K-outer for this GEMM, so the MFMA fragments (8
+// consecutive k = pixels of one channel per lane) are read TRANSPOSED from an LDS image [16 pixels][BM channels] per piece:
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block (verified on the device:
+// tests/bin/tr_probe), two of them make one bf16x8 fragment.  Row stride BM*2 + 64 bytes (= 16 banks mod 64): the 4 rows x 2
+// column blocks a 32-lane half reads fall on 64 distinct banks.
+// Structure as the forward kernel: 8 math + 4 loader waves, 16-deep chunks (16 pixels), two chunks of loads in flight, one
+// barrier per chunk; every split of the pixel range writes its own fp32 slab, wgrad_reduce_kernel sums them (igemm_conv.hip).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct X3WgArgs {
+    const uint32_t* xdy;  // packed dy  [P][nbCo][3][16]
+    const uint32_t* xs;   // packed (transformed) source [P][nbC][3][16]
+    int N, H, W, nbCo, nbC;
+    int Cout, Jtot, Kc, ksize, dil, cen;
+    float* slab;          // [S][Cout][Jtot]
+    int nCot, nJt, cps, nchunks;
+};
+
+template <int BM>
+__global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
+    constexpr int MW = 8, BN = BM, NB = BM / 16;
+    constexpr int U = NB * 6 / 16;                      // 16-byte units per loader thread, operand and chunk (its pixel: 16 threads x U)
+    constexpr int RS = BM * 2 + 64;                     // bytes per pixel row of one piece
+    constexpr int PLANE = 16 * RS, OPND = 3 * PLANE, TILE = 2 * OPND;      // bytes
+    constexpr int TM = BM / 128, TN = BM / 64;          // 32 x 32 blocks per math wave: wave tile (BM/4) x (BN/2)
+    extern __shared__ __attribute__((aligned(16))) char smemw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) >= MW;
+    const int cot = blockIdx.x / a.nJt, jt = blockIdx.x % a.nJt, split = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const int64_t P = (int64_t)a.N * H * W;
+    const int c0 = split * a.cps, c1 = min(a.nchunks, c0 + a.cps), n = c1 - c0;
+
+    // ------------------------------------------------------------------ loader state
+    const int lt = (tid - MW * 64) & 255, ps = lt >> 4, li = lt & 15;
+    int aoff[U], boff[U], btap[U];                      // 16-byte unit offsets relative to the pixel row; packed (dh, dw) of the unit's tap
+    unsigned aval = 0, bval = 0;                        // per-unit "block exists" bits
+    uint4 ar0[U], br0[U], ar1[U], br1[U];
+    int pcur = c0 * 16 + ps, hcur = 0, wcur = 0;
+    const int rowDy = a.nbCo * 6, rowS = a.nbC * 6;
+    if (loader) {
+        const int q = (int)(pcur < P ? pcur : 0);
+        wcur = q % W;
+        hcur = (q / W) % H;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
+            const int gb = cot * NB + b;
+            aoff[i] = gb * 6 + part;
+            aval |= (gb < a.nbCo ? 1u : 0u) << i;
+            const int j0 = (jt * NB + b) * 16;
+            int t = 0, cib = j0 / 16;
+            if (a.ksize >= 2) {
+                t = j0 / a.Kc;
+                cib = (j0 - t * a.Kc) / 16;
+            }
+            const int th = a.ksize == 3 ? t / 3 : t >> 1;
+            const int dh = a.ksize >= 2 ? (th - a.cen) * a.dil : 0, dw = a.ksize >= 2 ? (t - th * a.ksize - a.cen) * a.dil : 0;
+            boff[i] = (dh * W + dw) * rowS + cib * 6 + part;
+            btap[i] = (dh << 16) | (dw & 0xffff);
+            bval |= (j0 < a.Jtot ? 1u : 0u) << i;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(a.xdy), 0, (int)min((int64_t)0x7fffffff, P * rowDy * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(a.xs), 0, (int)min((int64_t)0x7fffffff, P * rowS * 16), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+
+    auto issue = [&](uint4 (&ar)[U], uint4 (&br)[U]) {
+        const bool pin = pcur < (int)P;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const bool oka = pin && ((aval >> i) & 1u);
+            ar[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yres, oka ? (pcur * rowDy + aoff[i]) * 16 : OOB, 0, 0));
+            const int hh = hcur + (btap[i] >> 16), ww = wcur + (int)(short)(btap[i] & 0xffff);
+            const bool okb = pin && ((bval >> i) & 1u) && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(sres, okb ? (pcur * rowS + boff[i]) * 16 : OOB, 0, 0));
+        }
+        pcur += 16;                 // next chunk: 16 pixels on
+        wcur += 16;
+        while (wcur >= W) {
+            wcur -= W;
+            if (++hcur >= H) hcur = 0;
+        }
+    };
+    auto stage = [&](const uint4 (&ar)[U], const uint4 (&br)[U], char* buf) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
+            const int off = (part >> 1) * PLANE + ps * RS + (b * 16 + (part & 1) * 8) * 2;
+            *reinterpret_cast<uint4*>(buf + off) = ar[i];
+            *reinterpret_cast<uint4*>(buf + OPND + off) = br[i];
+        }
+    };
+
+    if (loader) {
+        if (n > 0) {
+            issue(ar0, br0);
+            if (n > 1) issue(ar1, br1);
+            stage(ar0, br0, smemw);
+            if (n > 2) issue(ar0, br0);
+        }
+        __syncthreads();
+        for (int c = 0; c < n; c += 2) {
+            if (c + 1 < n) {
+                stage(ar1, br1, smemw + TILE);
+                if (c + 3 < n) issue(ar1, br1);
+            }
+            __syncthreads();
+            if (c + 1 < n) {
+                if (c + 2 < n) {
+                    stage(ar0, br0, smemw);
+                    if (c + 4 < n) issue(ar0, br0);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        const int wm = wave >> 1, wn = wave & 1;
+        const int g = lane >> 4, l = lane & 15;
+        // transposed-read address of this lane inside a piece plane, for the block at channel offset 0: rows 8*(g>>1) + (l>>2)
+        // (+4 for the second half of the k-octet), columns 16*(g&1) + 4*(l&3)
+        const int trbase = (8 * (g >> 1) + (l >> 2)) * RS + (16 * (g & 1) + 4 * (l & 3)) * 2;
+        const int abase = trbase + wm * (BM / 4) * 2, bbase = trbase + wn * (BN / 2) * 2;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto frag = [&](const char* plane, int off) -> bf16x8 {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off + 4 * RS));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(1);
+        for (int c = 0; c < n; ++c) {
+            const char* As = smemw + (c & 1) * TILE;
+            const char* Bs = As + OPND;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[q] = frag(As + q * PLANE, abase + 64 * i);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (BM == 256) asm volatile("" ::: "memory");
+                    bf16x8 bq[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bq[q] = frag(Bs + q * PLANE, bbase + 64 * j);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bq[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bq[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bq[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[0], acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        float* slab = a.slab + (int64_t)split * a.Cout * a.Jtot;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = jt * BN + wn * (BN / 2) + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = cot * BM + wm * (BM / 4) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < a.Cout && col < a.Jtot) slab[(int64_t)row * a.Jtot + col] = acc[i][j][r];
+                }
+            }
+    }
+}
+
+// Eligibility of the weight gradient: 16-wide channel blocks must not straddle taps (Kc % 16 == 0), enough work to pay for the
+// packing of dy (the source's packed form usually exists already from the forward conv).
+bool wgrad_x3_eligible(int Cin, int Cout, int ksize, int64_t P) {
+    return Cin % 16 == 0 && Cin >= 32 && ksize >= 2 && Cout >= 96 && P >= 4096;
+}
+
+int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_src, const void* x3_dy, hipStream_t st, int& S_out) {
+    UDA_REQUIRE(x3_src && x3_dy && uda_aligned16(x3_src) && uda_aligned16(x3_dy),
+                "uda_conv_wgrad (bf16x3): the packed operands x3_src / x3_dy are missing (uda_x3_pack; uda_conv_wgrad_uses_x3)");
+    const int64_t lim = (int64_t)1 << 31;
+    const int nbCo = x3_nb(k.Cout), nbC = x3_nb(k.src.C);
+    UDA_REQUIRE((P + 64) * nbCo * 6 < lim / 16 && (P + 64 + 4 * k.src.W * k.dil) * nbC * 6 < lim / 16,
+                "uda_conv_wgrad (bf16x3): operand too large for the 32-bit offsets of the wide-tile kernel");
+    const bool big = k.Cout >= 192 && k.Jtot >= 256 && P >= 65536;
+    const int BM = big ? 256 : 128;
+    X3WgArgs x;
+    x.xdy = reinterpret_cast<const uint32_t*>(x3_dy); x.xs = reinterpret_cast<const uint32_t*>(x3_src);
+    x.N = k.src.N; x.H = k.src.H; x.W = k.src.W; x.nbCo = nbCo; x.nbC = nbC;
+    x.Cout = k.Cout; x.Jtot = k.Jtot; x.Kc = k.Kc; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen;
+    x.slab = k.slab;
+    x.nCot = uda_cdiv(k.Cout, BM); x.nJt = uda_cdiv(k.Jtot, BM);
+    x.nchunks = uda_cdiv(P, X3_BK);
+    int S = (big ? 512 : 1024) / (x.nCot * x.nJt);
+    if (S > x.nchunks / 8) S = x.nchunks / 8;
+    if (S > S_max) S = S_max;           // the caller's slab holds S_max splits
+    if (S < 1) S = 1;
+    x.cps = uda_cdiv(x.nchunks, S);
+    S = uda_cdiv(x.nchunks, x.cps);
+    S_out = S;
+    static bool configured = false;
+    const size_t lds256 = 2 * 2 * 3 * 16 * (256 * 2 + 64), lds128 = 2 * 2 * 3 * 16 * (128 * 2 + 64);
+    if (!configured) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (e0 != hipSuccess || e1 != hipSuccess) return uda_set_error("igemm_wgrad_x3: cannot reserve LDS");
+        configured = true;
+    }
+    if (big) hipLaunchKernelGGL(igemm_wgrad_x3_kernel<256>, dim3(x.nCot * x.nJt, S), dim3(768), lds256, st, x);
+    else hipLaunchKernelGGL(igemm_wgrad_x3_kernel<128>, dim3(x.nCot * x.nJt, S), dim3(768), lds128, st, x);
+    UDA_LAUNCH_CHECK("igemm_wgrad_x3");
+    return 0;
+}

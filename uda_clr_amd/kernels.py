@@ -37,7 +37,8 @@ class UdaConvArgs(C.Structure):
 class UdaWgradArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("dy", C.c_void_p), ("lddy", C.c_int64), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("dil", C.c_int32), ("origin", C.c_int32), ("dw", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64), ("mfma", C.c_int32), ("_pad3", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64), ("mfma", C.c_int32), ("_pad3", C.c_int32),
+                ("x3_src", C.c_void_p), ("x3_dy", C.c_void_p)]
 
 
 # every symbol declared in include/uda_clr_hip.h: name -> (restype, argtypes)
@@ -54,6 +55,7 @@ SYMBOLS = {
     "uda_x3_pack": (_I, [C.POINTER(UdaSrc), _P, _P]),
     "uda_conv_wgrad_workspace_bytes": (_U, [_L, _I, _I, _I]),
     "uda_conv_wgrad": (_I, [C.POINTER(UdaWgradArgs), _P]),
+    "uda_conv_wgrad_uses_x3": (_I, [C.POINTER(UdaWgradArgs)]),
     "uda_dwconv_workspace_bytes": (_U, [_L, _I]),
     "uda_dwconv_fwd": (_I, [C.POINTER(UdaSrc), _P, _I, _I, _I, _P, _L, _P, _P]),
     "uda_dwconv_dgrad": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
@@ -284,9 +286,16 @@ class HipKernels:
             # weight, so an activation read by several convolutions (the ASPP input) and a weight used by several passes of one
             # step are split once.
             xs = getattr(src, "_x3", None)
+            if xs is None and not src.lazy:
+                xs = getattr(src.x, "_x3", None)        # a raw operand (dy) packed earlier for the weight gradient
             if xs is None:
                 xs = self.x3_pack(a.src, src.P, src.C, out.device)
                 src._x3 = xs
+                if not src.lazy:
+                    try:
+                        src.x._x3 = xs
+                    except AttributeError:
+                        pass
             xw = getattr(w, "_x3", None)
             if xw is None:
                 xw = self.x3_pack_rows(w)
@@ -303,6 +312,9 @@ class HipKernels:
         out = torch.empty(int(self.lib.uda_x3_packed_bytes(rows, K)), dtype=torch.uint8, device=device)
         self._ck(self.lib.uda_x3_pack(C.byref(usrc), out.data_ptr(), self._stream()))
         return out
+
+    def x3_pack_act(self, act: Act):
+        return self.x3_pack(self._src(act), act.P, act.C, act.x.device)
 
     def x3_pack_rows(self, w):
         """a relayouted weight [rows, taps, K'] (contiguous rows) as packed rows"""
@@ -334,6 +346,21 @@ class HipKernels:
         ws = self._ws(dy, self.lib.uda_conv_wgrad_workspace_bytes(src.P, Cout, src.C, ksize))
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.mfma = self.mfma
+        if self.mfma != self.MFMA_F32 and self.lib.uda_conv_wgrad_uses_x3(C.byref(a)):
+            # bf16x3: the source's packed form usually exists already (the forward conv packed the same descriptor); dy is packed
+            # once for its input-gradient conv and this weight gradient (the packed form rides on the tensor object)
+            xs = getattr(src, "_x3", None)
+            if xs is None:
+                xs = self.x3_pack(a.src, src.P, src.C, dy.device)
+                src._x3 = xs
+            xd = getattr(dy, "_x3", None)
+            if xd is None:
+                xd = self.x3_pack_act(Act(dy, src.N, src.H, src.W))
+                try:
+                    dy._x3 = xd
+                except AttributeError:
+                    pass
+            a.x3_src, a.x3_dy = xs.data_ptr(), xd.data_ptr()
         self._ck(self.lib.uda_conv_wgrad(C.byref(a), self._stream()))
 
     # ------------------------------------------------------------------ depthwise

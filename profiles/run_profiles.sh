@@ -7,7 +7,7 @@ set -o pipefail
 # (default: the bf16x3 dominant kernel; 'igemm_conv_ws_kernel<3' with EXTRA="--mfma f32").
 OUT=${1:-gpurun_out/prof}; shift
 WHAT=${@:-pf so rn pmc}
-EXTRA="${EXTRA:-} --no-other-mfma"
+EXTRA="${EXTRA:-} --no-other-mfma --no-host-input"
 PMC_MATCH=${PMC_MATCH:-igemm_conv_x3_kernel<3}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -27,7 +27,7 @@ for w in $WHAT; do
   MARK=stem_fwd_kernel; [ $w = rn ] && MARK=stem7_fwd_kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w -o $w -- python3 bench.py $ARGS $EXTRA > $OUT/${w}_bench.log 2>&1 || exit 1
   grep '^{' $OUT/${w}_bench.log | tail -1 > $OUT/${w}_bench_line.json
-  python3 profiles/summarize_trace.py $(find $OUT/$w -name '*kernel_trace.csv') --marker $MARK --per-step $PER --warmup 2 --steps 5 > $OUT/${w}_summary.txt || exit 1
+  python3 profiles/summarize_trace.py $(find $OUT/$w -name '*kernel_trace.csv') --marker $MARK --per-step $PER --warmup 2 --steps 5 --by-grid "${BY_GRID:-_x3_kernel,igemm_conv_kernel,igemm_conv_ws_kernel,igemm_wgrad}" > $OUT/${w}_summary.txt || exit 1
   cp $(find $OUT/$w -name '*kernel_stats.csv') $OUT/${w}_kernel_stats.csv
   rm -rf $OUT/$w
   echo "$w done"

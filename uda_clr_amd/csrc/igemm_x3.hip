@@ -48,7 +48,9 @@ __device__ __forceinline__ void x3_split2(float v0, float v1, uint32_t& p1, uint
     p3 = __builtin_bit_cast(uint32_t, c);
 }
 
-// one thread: 8 consecutive k of one row -> 3 x 16 B.  XF as in the conv kernels (0 raw, 1 BN + act, 2 + keep-mask).
+// one thread: 8 consecutive k of one row -> 3 x 16 B; a workgroup's 256 octets are consecutive in the output ([row][block] order,
+// 48 B each), so the 12 KB it produces are staged in LDS in output order and stored as three fully coalesced 4 KB rows.
+// XF as in the conv kernels (0 raw, 1 BN + act, 2 + keep-mask).
 struct X3PackArgs {
     uda_src_t src;        // activations [P, ldx] with the pending transform; for weight rows: x = rows, C = Ktot, no transform
     int64_t P;
@@ -58,42 +60,53 @@ struct X3PackArgs {
 
 template <int XF>
 __global__ __launch_bounds__(256) void x3_pack_kernel(X3PackArgs a) {
-    const int C = a.src.C, no = a.nb * 2;                        // octets per row
-    const int64_t total = a.P * no;
+    __shared__ uint4 stg[768];
+    const int C = a.src.C, no = a.nb * 2, tid = threadIdx.x;     // octets per row
+    const int64_t total = a.P * no, ntiles = (total + 255) >> 8;
     const float alo = a.src.act == ACT_NONE ? -INFINITY : 0.f, ahi = a.src.act == ACT_RELU6 ? 6.f : INFINITY;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int o = (int)(e % no);
-        const int64_t p = e / no;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t e0 = tile << 8, p0 = e0 / no;
+        const int oo = (int)(e0 - p0 * no) + tid, dp = oo / no, o = oo - dp * no;
+        const int64_t p = p0 + dp;
         const int c0 = o * 8;
-        float v[8];
+        uint32_t q1[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0}, q3[4] = {0, 0, 0, 0};
+        if (e0 + tid < total) {
+            float v[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = c0 + 4 * h;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C) x = uda_ld4(a.src.x + p * a.src.ldx + c);          // rows hold round4(C) readable floats
-            float t[4] = {x.x, x.y, x.z, x.w};
-            if (XF >= 1) {
-                uint32_t mk = 0x01010101u;
-                if (XF == 2 && c < C) mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 4 * h;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < C) x = uda_ld4(a.src.x + p * a.src.ldx + c);          // rows hold round4(C) readable floats
+                float t[4] = {x.x, x.y, x.z, x.w};
+                if (XF >= 1) {
+                    uint32_t mk = 0x01010101u;
+                    if (XF == 2 && c < C) mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = (c + j) < C;
-                    const float sc = (ok && a.src.scale) ? a.src.scale[c + j] : 1.f, sh = (ok && a.src.shift) ? a.src.shift[c + j] : 0.f;
-                    float u = __builtin_amdgcn_fmed3f(t[j] * sc + sh, alo, ahi);
-                    if (XF == 2) u *= ((mk >> (8 * j)) & 0xffu) ? a.src.mask_scale : 0.f;
-                    t[j] = u;
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = (c + j) < C;
+                        const float sc = (ok && a.src.scale) ? a.src.scale[c + j] : 1.f, sh = (ok && a.src.shift) ? a.src.shift[c + j] : 0.f;
+                        float u = __builtin_amdgcn_fmed3f(t[j] * sc + sh, alo, ahi);
+                        if (XF == 2) u *= ((mk >> (8 * j)) & 0xffu) ? a.src.mask_scale : 0.f;
+                        t[j] = u;
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * h + j] = (c + j) < C ? t[j] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * h + j] = (c + j) < C ? t[j] : 0.f;
+            for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
         }
-        uint32_t q1[4], q2[4], q3[4];
+        const int sl = (tid >> 1) * 6 + (tid & 1);               // uint4 slots: block (tid >> 1) holds [piece][half]
+        stg[sl] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        stg[sl + 2] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        stg[sl + 4] = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(a.out) + e0 * 3;
+        const int64_t left = (total - e0) * 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
-        uint32_t* d = a.out + ((p * a.nb + (o >> 1)) * 3) * 8 + (o & 1) * 4;          // dwords: 8 per 16 bf16
-        *reinterpret_cast<uint4*>(d) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        *reinterpret_cast<uint4*>(d + 8) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        *reinterpret_cast<uint4*>(d + 16) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        for (int r = 0; r < 3; ++r)
+            if (r * 256 + tid < left) dst[r * 256 + tid] = stg[r * 256 + tid];
+        __syncthreads();
     }
 }
 
@@ -198,15 +211,20 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             const bool ok = kval && ((vmask3[i / 3] >> (9 * (i % 3) + (KS == 3 ? t : 0))) & 1u);
             ar[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (aoff[i] + xoff) * 16 : OOB, 0, 0));
         }
-        const int woff = chunk * 6;
+        const int woff = (KS == 3 ? (((blk >> 1) * T + t) * 2 + half) : chunk) * 6;
 #pragma unroll
         for (int i = 0; i < B_U; ++i)
             br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, (boff[i] + woff) * 16, 0, 0));
         ++chunk;
-        if (KS == 3) {          // halves of a 32-channel slice share the tap; then the next tap; after T taps the next slice
-            if ((half ^= 1) == 0 && ++t_cur == T) {
+        if (KS == 3) {
+            if (a.debug & 8) {  // (old order, diagnostics) halves of a 32-channel slice share the tap; then the next tap
+                if ((half ^= 1) == 0 && ++t_cur == T) {
+                    t_cur = 0;
+                    blk += 2;
+                }
+            } else if (++t_cur == T) {      // all taps of one 16-channel block (its pixels stay in L2 for the T re-reads), then the next
                 t_cur = 0;
-                blk += 2;
+                if ((half ^= 1) == 0) blk += 2;
             }
         } else {
             blk += 1;
@@ -371,7 +389,7 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st) {
 // Eligibility: the tap-chunked K order (>= 32 channels per tap), and enough MFMA work per packed element to pay for the packing
 // pass (2 * Cout * taps FLOPs per activation element): the multi-tap convs with Cout * taps >= 768 (measured: 3x3 / 2x2 convs with
 // 256 outputs run 1.5-1.7x faster incl. the pass, a 1x1 1280 -> 256 conv 0.8x).
-bool conv_x3_eligible(const ConvKArgs& k) { return k.Kc >= IG_BK && k.ksize >= 2 && k.Cout * k.ksize * k.ksize >= 768; }
+bool conv_x3_eligible(const ConvKArgs& k) { return k.Kc >= IG_BK && k.ksize >= 2 && k.Cout * k.ksize * k.ksize >= 512; }
 
 static inline int x3_nb(int C) { return uda_cdiv(C, X3_BK); }
 

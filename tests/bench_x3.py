@@ -30,7 +30,9 @@ cases = [("decoder conv4 fwd masked B=16", 16, 128, 128, 256, 256, 3, 1, True, T
          ("conv4 dgrad raw B=16", 16, 128, 128, 256, 256, 3, 1, False, False),
          ("ASPP atrous d=6 B=16", 16, 32, 32, 320, 256, 3, 6, True, False),
          ("disc L3 2x2 128->256 B=16", 16, 67, 67, 512, 256, 2, 1, False, False),
-         ("1x1 1280->256 B=16", 16, 32, 32, 1280, 256, 1, 1, True, False)]
+         ("1x1 1280->256 B=16", 16, 32, 32, 1280, 256, 1, 1, True, False),
+         ("1x1 tap GEMM 256->2304 B=32", 32, 32, 32, 256, 2304, 1, 1, False, False),
+         ("1x1 tap GEMM 256->2304 B=16", 16, 32, 32, 256, 2304, 1, 1, False, False)]
 if os.environ.get("X3_ONLY"):
     cases = [c for c in cases if os.environ["X3_ONLY"] in c[0]]
 for name, N, H, W, Cin, Cout, k, dil, lazy, mask in cases:

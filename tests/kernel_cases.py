@@ -791,6 +791,16 @@ CASES += [
     ("wgrad3x3 48->100 P=4700 ragged (x3)", case_wgrad(2, 50, 47, 48, 100, 3, 1)),
     ("wgrad2x2 o0 256->128 P=8978 (x3)", case_wgrad(2, 67, 67, 256, 128, 2, 1, lazy=False, origin=0)),
     ("wgrad2x2 o0 64->200 P=70225 (x3 256 tiles, ragged)", case_wgrad(1, 265, 265, 64, 200, 2, 1, lazy=False, origin=0)),
+    ("wgrad1x1 256->2304 P=4608 (x3, tap GEMM of the re-associated decoder conv)", case_wgrad(2, 48, 48, 256, 2304, 1, 1, lazy=False)),
+    ("wgrad2x2 o0 1024->512 P=9248 (x3 256 tiles on few pixels)", case_wgrad(2, 68, 68, 1024, 512, 2, 1, lazy=False, origin=0)),
+]
+# bf16x3 routes added with the 256 x 64 tile and the wide 1x1 route
+CASES += [
+    ("conv1x1 256->2304 stats (x3 wide 1x1)", case_conv(2, 40, 36, 256, 2304, 1, 1, lazy=False)),
+    ("conv1x1 144->1030 relu6 ragged (x3 wide 1x1)", case_conv(1, 37, 29, 144, 1030, 1, 1)),
+    ("conv3x3 256->48 P=2442 ragged (x3 256 x 64 tile)", case_conv(2, 33, 37, 256, 48, 3, 1, lazy=False)),
+    ("conv3x3 160->60 dil2 mask stats (x3 256 x 64 tile)", case_conv(1, 45, 41, 160, 60, 3, 2, mask=True)),
+    ("conv2x2 o1 256->56 addend (x3 256 x 64 tile)", case_conv(2, 30, 30, 256, 56, 2, 1, lazy=False, addend=True, origin=1)),
 ]
 
 

@@ -429,7 +429,8 @@ static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
 static bool conv_is_wide(const uda_conv_args_t* a, int Kc, int Ktot) {
     if (a->Cout == 1 && !a->src.scale && !a->src.mask && a->src.act == ACT_NONE && !a->stats && Ktot >= 1024) return false;
     if (a->Cout <= 2 && a->ksize == 1 && !a->stats && Kc >= 64 && Kc <= 2048) return false;
-    if (a->Cout <= 96) return false;
+    if (a->Cout <= 96)      // narrow outputs: only the bf16x3 mode has a 64-column wide tile (long-K multi-tap convs)
+        return a->mfma == UDA_MFMA_BF16X3 && a->ksize >= 2 && a->Cout >= 40 && a->Cout <= 64 && Kc >= 128 && Ktot >= 1024;
     if (Ktot <= 192 || (a->ksize >= 2 && Kc < IG_BK)) return false;
     return true;
 }
@@ -485,7 +486,8 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
         UDA_LAUNCH_CHECK("conv_heads");
         return 0;
     }
-    if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
+    if (uda_conv_uses_x3(a)) e = launch_conv_x3(k, P, a->x3_src, a->x3_w, st);
+    else if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
     else if (k.Ktot <= 192 || (a->ksize >= 2 && k.Kc < IG_BK)) {     // (the wide-tile kernel only walks the tap-chunked K order)

@@ -131,8 +131,9 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     constexpr int WMM = BM / 64, WNN = MW / WMM, TNW = 2 * TN / WNN;
     static_assert(WMM * WNN == MW && (2 * TN) % WNN == 0, "math-wave grid must tile the workgroup tile");
     constexpr int NTHR = (MW + 4) * 64;
-    constexpr int A_U = BM * 6 / 256, B_U = BN * 6 / 256;        // 16-byte units (row, piece, octet) per loader thread and chunk
-    static_assert((BM * 6) % 256 == 0 && (BN * 6) % 256 == 0, "units must divide over the 256 loader threads");
+    constexpr int A_U = BM * 6 / 256, B_UNITS = BN * 6, B_U = (B_UNITS + 255) / 256;   // 16-byte units (row, piece, octet) per loader thread and chunk
+    static_assert((BM * 6) % 256 == 0, "A units must divide over the 256 loader threads");
+    constexpr bool B_FULL = B_UNITS % 256 == 0;                  // 64-column tiles: the last B unit only on the first 128 loader threads
     constexpr int TILE = (BM + BN) * X3_ROW;                     // bf16 elements per buffer
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < B_U; ++i) {
-            const int u = lt + 256 * i, row = unit_row(u), part = u - row * 6;
+            const int u = min(lt + 256 * i, B_UNITS - 1), row = unit_row(u), part = u - row * 6;
             const int n = min(n0 + row, a.Cout - 1);
             boff[i] = n * (nchunks * 6) + part;
         }
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
 #pragma unroll
         for (int i = 0; i < A_U; ++i) *reinterpret_cast<uint4*>(As + 16 * (lt + 256 * i + unit_row(lt + 256 * i))) = ar[i];
 #pragma unroll
-        for (int i = 0; i < B_U; ++i) *reinterpret_cast<uint4*>(Bs + 16 * (lt + 256 * i + unit_row(lt + 256 * i))) = br[i];
+        for (int i = 0; i < B_U; ++i)
+            if (B_FULL || lt + 256 * i < B_UNITS) *reinterpret_cast<uint4*>(Bs + 16 * (lt + 256 * i + unit_row(lt + 256 * i))) = br[i];
     };
 
     // ------------------------------------------------------------------ math state
@@ -387,9 +389,14 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st) {
 }
 
 // Eligibility: the tap-chunked K order (>= 32 channels per tap), and enough MFMA work per packed element to pay for the packing
-// pass (2 * Cout * taps FLOPs per activation element): the multi-tap convs with Cout * taps >= 768 (measured: 3x3 / 2x2 convs with
-// 256 outputs run 1.5-1.7x faster incl. the pass, a 1x1 1280 -> 256 conv 0.8x).
-bool conv_x3_eligible(const ConvKArgs& k) { return k.Kc >= IG_BK && k.ksize >= 2 && k.Cout * k.ksize * k.ksize >= 512; }
+// pass (2 * Cout * taps FLOPs per activation element).  Measured (tests/bench_x3.py, profiles/r02_bf16x3_vs_f32_conv_microbench.txt):
+// 3x3 / 2x2 convs with >= 128 outputs run 1.5-2.0x faster incl. the pass; a 3x3 conv towards 48 channels over K = 2304 1.9x on
+// the 256 x 64 tile; 1x1 convs only when very wide (256 -> 2304 tap GEMM of the re-associated decoder conv: 1.6-1.8x; 1280 -> 256
+// at 16384 pixels: 1.0x, stays on the fp32 pipe).
+bool conv_x3_eligible(const ConvKArgs& k) {
+    if (k.ksize == 1) return k.Kc >= 128 && k.Cout >= 1024;
+    return k.Kc >= IG_BK && k.Cout * k.ksize * k.ksize >= 432;
+}
 
 static inline int x3_nb(int C) { return uda_cdiv(C, X3_BK); }
 
@@ -431,6 +438,7 @@ int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w
     const bool tall = wide && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
     const bool mid = wide && uda_cdiv(P, 128) * uda_cdiv(k.Cout, 256) >= 256;
     if (k.ksize >= 2) {
+        if (k.Cout <= 64) return launch_x3<3, 1, 256>(x, P, st);      // input gradient towards a narrow tensor (decoder low-level branch)
         if (tall) return launch_x3<3, 4, 256>(x, P, st);
         if (mid) return launch_x3<3, 4, 128>(x, P, st);
         return launch_x3<3, 2, 128>(x, P, st);
@@ -626,7 +634,8 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
 // Eligibility of the weight gradient: 16-wide channel blocks must not straddle taps (Kc % 16 == 0), enough work to pay for the
 // packing of dy (the source's packed form usually exists already from the forward conv).
 bool wgrad_x3_eligible(int Cin, int Cout, int ksize, int64_t P) {
-    return Cin % 16 == 0 && Cin >= 32 && ksize >= 2 && Cout >= 96 && P >= 4096;
+    if (ksize == 1) return Cin % 16 == 0 && Cin >= 128 && Cout >= 1024 && P >= 4096;
+    return Cin % 16 == 0 && Cin >= 32 && Cout >= 96 && P >= 4096;
 }
 
 int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_src, const void* x3_dy, hipStream_t st, int& S_out) {
@@ -636,7 +645,7 @@ int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_sr
     const int nbCo = x3_nb(k.Cout), nbC = x3_nb(k.src.C);
     UDA_REQUIRE((P + 64) * nbCo * 6 < lim / 16 && (P + 64 + 4 * k.src.W * k.dil) * nbC * 6 < lim / 16,
                 "uda_conv_wgrad (bf16x3): operand too large for the 32-bit offsets of the wide-tile kernel");
-    const bool big = k.Cout >= 192 && k.Jtot >= 256 && P >= 65536;
+    const bool big = k.Cout >= 192 && k.Jtot >= 256 && P >= 8192;     // 128 x 128 tiles stage 64 B per MFMA clock and CU: load-bound
     const int BM = big ? 256 : 128;
     X3WgArgs x;
     x.xdy = reinterpret_cast<const uint32_t*>(x3_dy); x.xs = reinterpret_cast<const uint32_t*>(x3_src);

@@ -33,9 +33,17 @@ def gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def _poison(buf):
+    """Fill a float matrix with what an uninitialised buffer may hold: NaN, +-Inf and huge finite values by row (the fused
+    clamps swallow a NaN, so NaN alone would not show a padding lane that takes part in a sum; Inf * 0 does)."""
+    vals = torch.tensor([float("nan"), float("inf"), -float("inf"), 3.0e38], dtype=buf.dtype, device=buf.device)
+    buf.copy_(vals[torch.arange(buf.shape[0], device=buf.device) % 4].unsqueeze(1).expand_as(buf))
+    return buf
+
+
 def padded(P, C, g, dev=None, scale=1.0, dtype=torch.float32):
-    """[P, C] view of a [P, round4(C)+4] buffer whose padding holds NaN (must never leak)."""
-    buf = torch.full((P, round4(C) + 4), float("nan"), dtype=dtype)
+    """[P, C] view of a [P, round4(C)+4] buffer whose padding holds NaN / Inf / huge values (must never leak)."""
+    buf = _poison(torch.empty((P, round4(C) + 4), dtype=dtype))
     buf[:, :C] = torch.randn(P, C, generator=g) * scale
     if dev is not None:
         buf = buf.to(dev)
@@ -49,7 +57,9 @@ def to_dev(t, dev):
     if t.dim() == 2 and t.stride(0) != t.shape[1]:
         base = torch.empty(t.shape[0], t.stride(0), dtype=t.dtype, device=dev)
         if t.dtype.is_floating_point:
-            base.fill_(float("nan"))
+            _poison(base)
+        elif t.dtype == torch.uint8:
+            base.copy_((torch.arange(base.numel(), device=dev) % 251).to(torch.uint8).view_as(base))      # keep-mask padding: arbitrary bytes
         v = base[:, :t.shape[1]]
         v.copy_(t)
         return v

@@ -29,6 +29,19 @@ def test_train_forward_backward_matches_oracle(size):
     assert gmean < 1.5, gmean
 
 
+def test_padding_columns_never_leak(monkeypatch):
+    """Every fp32 work matrix of the engine starts as NaN / +-Inf / 3e38 (its [P, round4(C)] padding columns are never written):
+    outputs and gradients must be the same as on clean buffers.  (A head kernel that relied on zero WEIGHTS to cancel the
+    padding lanes produced Inf * 0 = NaN logits whenever the allocator handed it a block with large values in it.)"""
+    from uda_clr_amd import engine
+    monkeypatch.setattr(engine, "POISON_BUFFERS", True)
+    fwd, grads, stats, _ = model_cases.train_parity(DEV, S=96)
+    assert max(fwd.values()) < 1e-3, fwd
+    assert stats < 1e-3
+    bad, gmean = model_cases.grads_ok(grads)
+    assert not bad, list(bad.items())[:10]
+
+
 @pytest.mark.parametrize("tag", ["64", "512"])
 def test_matches_reference_fixtures(tag):
     errs = model_cases.golden_parity(DEV, tag)

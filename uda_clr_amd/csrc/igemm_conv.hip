@@ -383,17 +383,24 @@ __global__ __launch_bounds__(256) void conv_heads_kernel(ConvKArgs a) {
             const float* xr = a.src.x + p * a.src.ldx;
             for (int g = l16; g < G; g += 16) {
                 const int c = g * 4;
-                const float4 xv = uda_ld4(xr + c), sc = uda_ld4(&hsm[c]), sh = uda_ld4(&hsm[Kc + c]);
+                float4 xv = uda_ld4(xr + c);
+                const float4 sc = uda_ld4(&hsm[c]), sh = uda_ld4(&hsm[Kc + c]);
+                if (c + 4 > C) {        // padding lanes of the last granule hold whatever the buffer held (Inf * 0 would be NaN)
+                    if (c + 1 >= C) xv.y = 0.f;
+                    if (c + 2 >= C) xv.z = 0.f;
+                    xv.w = 0.f;
+                }
                 float u[4] = {__builtin_amdgcn_fmed3f(xv.x * sc.x + sh.x, alo, ahi), __builtin_amdgcn_fmed3f(xv.y * sc.y + sh.y, alo, ahi),
                               __builtin_amdgcn_fmed3f(xv.z * sc.z + sh.z, alo, ahi), __builtin_amdgcn_fmed3f(xv.w * sc.w + sh.w, alo, ahi)};
                 if (a.src.mask) {
-                    const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
+                    uint32_t mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
+                    if (c + 4 > C) mk &= 0xffffffffu >> (8 * (c + 4 - C));
                     u[0] *= (float)(mk & 0xffu) * ms; u[1] *= (float)((mk >> 8) & 0xffu) * ms;
                     u[2] *= (float)((mk >> 16) & 0xffu) * ms; u[3] *= (float)(mk >> 24) * ms;
                 }
 #pragma unroll
                 for (int o = 0; o < NO; ++o) {
-                    const float4 wv = uda_ld4(&hsm[(2 + o) * Kc + c]);      // zero beyond C: garbage lanes of the last granule drop out
+                    const float4 wv = uda_ld4(&hsm[(2 + o) * Kc + c]);      // zero beyond C
                     acc[o] += u[0] * wv.x + u[1] * wv.y + u[2] * wv.z + u[3] * wv.w;
                 }
             }

@@ -469,13 +469,13 @@ struct X3WgArgs {
     int nCot, nJt, cps, nchunks;
 };
 
-template <int BM>
+template <int BM, int BN>
 __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
-    constexpr int MW = 8, BN = BM, NB = BM / 16;
-    constexpr int U = NB * 6 / 16;                      // 16-byte units per loader thread, operand and chunk (its pixel: 16 threads x U)
-    constexpr int RS = BM * 2 + 64;                     // bytes per pixel row of one piece
-    constexpr int PLANE = 16 * RS, OPND = 3 * PLANE, TILE = 2 * OPND;      // bytes
-    constexpr int TM = BM / 128, TN = BM / 64;          // 32 x 32 blocks per math wave: wave tile (BM/4) x (BN/2)
+    constexpr int MW = 8, NBA = BM / 16, NBB = BN / 16;
+    constexpr int UA = NBA * 6 / 16, UB = NBB * 6 / 16; // 16-byte units per loader thread and chunk (its pixel: 16 threads x U)
+    constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64; // bytes per pixel row of one piece
+    constexpr int PLA = 16 * RSA, PLB = 16 * RSB, OPA = 3 * PLA, TILE = OPA + 3 * PLB;      // bytes
+    constexpr int TM = BM / 128, TN = BN / 64;          // 32 x 32 blocks per math wave: wave tile (BM/4) x (BN/2)
     extern __shared__ __attribute__((aligned(16))) char smemw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -487,9 +487,9 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
 
     // ------------------------------------------------------------------ loader state
     const int lt = (tid - MW * 64) & 255, ps = lt >> 4, li = lt & 15;
-    int aoff[U], boff[U], btap[U];                      // 16-byte unit offsets relative to the pixel row; packed (dh, dw) of the unit's tap
+    int aoff[UA], boff[UB], btap[UB];                   // 16-byte unit offsets relative to the pixel row; packed (dh, dw) of the unit's tap
     unsigned aval = 0, bval = 0;                        // per-unit "block exists" bits
-    uint4 ar0[U], br0[U], ar1[U], br1[U];
+    uint4 ar0[UA], br0[UB], ar1[UA], br1[UB];
     int pcur = c0 * 16 + ps, hcur = 0, wcur = 0;
     const int rowDy = a.nbCo * 6, rowS = a.nbC * 6;
     if (loader) {
@@ -497,12 +497,16 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
         wcur = q % W;
         hcur = (q / W) % H;
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
+        for (int i = 0; i < UA; ++i) {
             const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
-            const int gb = cot * NB + b;
+            const int gb = cot * NBA + b;
             aoff[i] = gb * 6 + part;
             aval |= (gb < a.nbCo ? 1u : 0u) << i;
-            const int j0 = (jt * NB + b) * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+            const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
+            const int j0 = (jt * NBB + b) * 16;
             int t = 0, cib = j0 / 16;
             if (a.ksize >= 2) {
                 t = j0 / a.Kc;
@@ -521,12 +525,15 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
         const_cast<uint32_t*>(a.xs), 0, (int)min((int64_t)0x7fffffff, P * rowS * 16), 0x00020000);
     constexpr int OOB = 0x7ffffff0;
 
-    auto issue = [&](uint4 (&ar)[U], uint4 (&br)[U]) {
+    auto issue = [&](uint4 (&ar)[UA], uint4 (&br)[UB]) {
         const bool pin = pcur < (int)P;
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
+        for (int i = 0; i < UA; ++i) {
             const bool oka = pin && ((aval >> i) & 1u);
             ar[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yres, oka ? (pcur * rowDy + aoff[i]) * 16 : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
             const int hh = hcur + (btap[i] >> 16), ww = wcur + (int)(short)(btap[i] & 0xffff);
             const bool okb = pin && ((bval >> i) & 1u) && hh >= 0 && hh < H && ww >= 0 && ww < W;
             br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(sres, okb ? (pcur * rowS + boff[i]) * 16 : OOB, 0, 0));
@@ -538,13 +545,16 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
             if (++hcur >= H) hcur = 0;
         }
     };
-    auto stage = [&](const uint4 (&ar)[U], const uint4 (&br)[U], char* buf) {
+    auto stage = [&](const uint4 (&ar)[UA], const uint4 (&br)[UB], char* buf) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
+        for (int i = 0; i < UA; ++i) {
             const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
-            const int off = (part >> 1) * PLANE + ps * RS + (b * 16 + (part & 1) * 8) * 2;
-            *reinterpret_cast<uint4*>(buf + off) = ar[i];
-            *reinterpret_cast<uint4*>(buf + OPND + off) = br[i];
+            *reinterpret_cast<uint4*>(buf + (part >> 1) * PLA + ps * RSA + (b * 16 + (part & 1) * 8) * 2) = ar[i];
+        }
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+            const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
+            *reinterpret_cast<uint4*>(buf + OPA + (part >> 1) * PLB + ps * RSB + (b * 16 + (part & 1) * 8) * 2) = br[i];
         }
     };
 
@@ -575,8 +585,8 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
         const int g = lane >> 4, l = lane & 15;
         // transposed-read address of this lane inside a piece plane, for the block at channel offset 0: rows 8*(g>>1) + (l>>2)
         // (+4 for the second half of the k-octet), columns 16*(g&1) + 4*(l&3)
-        const int trbase = (8 * (g >> 1) + (l >> 2)) * RS + (16 * (g & 1) + 4 * (l & 3)) * 2;
-        const int abase = trbase + wm * (BM / 4) * 2, bbase = trbase + wn * (BN / 2) * 2;
+        const int trr = 8 * (g >> 1) + (l >> 2), trc = (16 * (g & 1) + 4 * (l & 3)) * 2;
+        const int abase = trr * RSA + trc + wm * (BM / 4) * 2, bbase = trr * RSB + trc + wn * (BN / 2) * 2;
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -584,27 +594,27 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        auto frag = [&](const char* plane, int off) -> bf16x8 {
+        auto frag = [&](const char* plane, int off, int rs) -> bf16x8 {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off + 4 * RS));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off + 4 * rs));
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
         __syncthreads();
         __builtin_amdgcn_s_setprio(1);
         for (int c = 0; c < n; ++c) {
             const char* As = smemw + (c & 1) * TILE;
-            const char* Bs = As + OPND;
+            const char* Bs = As + OPA;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 bf16x8 af[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) af[q] = frag(As + q * PLANE, abase + 64 * i);
+                for (int q = 0; q < 3; ++q) af[q] = frag(As + q * PLA, abase + 64 * i, RSA);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (BM == 256) asm volatile("" ::: "memory");
+                    if (BM * BN >= 256 * 256) asm volatile("" ::: "memory");
                     bf16x8 bq[3];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) bq[q] = frag(Bs + q * PLANE, bbase + 64 * j);
+                    for (int q = 0; q < 3; ++q) bq[q] = frag(Bs + q * PLB, bbase + 64 * j, RSB);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bq[0], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bq[1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bq[2], acc[i][j], 0, 0, 0);
@@ -645,16 +655,19 @@ int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_sr
     const int nbCo = x3_nb(k.Cout), nbC = x3_nb(k.src.C);
     UDA_REQUIRE((P + 64) * nbCo * 6 < lim / 16 && (P + 64 + 4 * k.src.W * k.dil) * nbC * 6 < lim / 16,
                 "uda_conv_wgrad (bf16x3): operand too large for the 32-bit offsets of the wide-tile kernel");
-    const bool big = k.Cout >= 192 && k.Jtot >= 256 && P >= 8192;     // 128 x 128 tiles stage 64 B per MFMA clock and CU: load-bound
-    const int BM = big ? 256 : 128;
+    // tiles (Cout x J): 256 x 256 for wide outputs; 128 x 256 otherwise (128 x 128 tiles would stage 64 B per MFMA clock and CU and
+    // are load-bound); 128 x 128 only for short J
+    const bool big = k.Cout >= 192 && k.Jtot >= 256 && P >= 8192;
+    const bool wideJ = !big && k.Jtot >= 256;
+    const int BM = big ? 256 : 128, BN = (big || wideJ) ? 256 : 128;
     X3WgArgs x;
     x.xdy = reinterpret_cast<const uint32_t*>(x3_dy); x.xs = reinterpret_cast<const uint32_t*>(x3_src);
     x.N = k.src.N; x.H = k.src.H; x.W = k.src.W; x.nbCo = nbCo; x.nbC = nbC;
     x.Cout = k.Cout; x.Jtot = k.Jtot; x.Kc = k.Kc; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen;
     x.slab = k.slab;
-    x.nCot = uda_cdiv(k.Cout, BM); x.nJt = uda_cdiv(k.Jtot, BM);
+    x.nCot = uda_cdiv(k.Cout, BM); x.nJt = uda_cdiv(k.Jtot, BN);
     x.nchunks = uda_cdiv(P, X3_BK);
-    int S = (big ? 512 : 1024) / (x.nCot * x.nJt);
+    int S = (big ? 512 : (wideJ ? 768 : 1024)) / (x.nCot * x.nJt);
     if (S > x.nchunks / 8) S = x.nchunks / 8;
     if (S > S_max) S = S_max;           // the caller's slab holds S_max splits
     if (S < 1) S = 1;
@@ -662,15 +675,18 @@ int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_sr
     S = uda_cdiv(x.nchunks, x.cps);
     S_out = S;
     static bool configured = false;
-    const size_t lds256 = 2 * 2 * 3 * 16 * (256 * 2 + 64), lds128 = 2 * 2 * 3 * 16 * (128 * 2 + 64);
+    auto ldsz = [](int bm, int bn) { return (size_t)2 * 3 * 16 * ((bm * 2 + 64) + (bn * 2 + 64)); };
     if (!configured) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        if (e0 != hipSuccess || e1 != hipSuccess) return uda_set_error("igemm_wgrad_x3: cannot reserve LDS");
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<256, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz(256, 256));
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz(128, 256));
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz(128, 128));
+        if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) return uda_set_error("igemm_wgrad_x3: cannot reserve LDS");
         configured = true;
     }
-    if (big) hipLaunchKernelGGL(igemm_wgrad_x3_kernel<256>, dim3(x.nCot * x.nJt, S), dim3(768), lds256, st, x);
-    else hipLaunchKernelGGL(igemm_wgrad_x3_kernel<128>, dim3(x.nCot * x.nJt, S), dim3(768), lds128, st, x);
+    const dim3 grid(x.nCot * x.nJt, S);
+    if (big) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<256, 256>), grid, dim3(768), ldsz(256, 256), st, x);
+    else if (wideJ) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<128, 256>), grid, dim3(768), ldsz(128, 256), st, x);
+    else hipLaunchKernelGGL((igemm_wgrad_x3_kernel<128, 128>), grid, dim3(768), ldsz(128, 128), st, x);
     UDA_LAUNCH_CHECK("igemm_wgrad_x3");
     return 0;
 }

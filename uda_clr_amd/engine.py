@@ -27,6 +27,8 @@ from typing import Dict, Optional
 
 import torch
 
+POISON_BUFFERS = False      # tests/test_generator_gpu.py sets it: every fp32 work matrix starts as NaN / Inf / huge values
+
 from .acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, BNRec, nchw_view, round4
 from .domain_split import DomainSplit
 
@@ -170,7 +172,12 @@ class GeneratorEngine:
 
     @staticmethod
     def _empty(x, *shape, dtype=torch.float32):
-        return torch.empty(shape, dtype=dtype, device=x.device)
+        t = torch.empty(shape, dtype=dtype, device=x.device)
+        if POISON_BUFFERS and dtype == torch.float32 and t.dim() == 2:
+            # tests: what an uninitialised buffer may hold (the padding columns of a [P, round4(C)] matrix are never written)
+            t.copy_(torch.tensor([float("nan"), float("inf"), -float("inf"), 3.0e38], device=x.device)[
+                torch.arange(t.shape[0], device=x.device) % 4].unsqueeze(1).expand_as(t))
+        return t
 
     def _buf(self, x, P, C):
         """[P, C] view of a fresh [P, round4(C)] buffer."""

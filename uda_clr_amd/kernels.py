@@ -285,17 +285,7 @@ class HipKernels:
             # bf16x3: both operands as their three bf16 pieces.  The packed forms are kept on the descriptor / the relayouted
             # weight, so an activation read by several convolutions (the ASPP input) and a weight used by several passes of one
             # step are split once.
-            xs = getattr(src, "_x3", None)
-            if xs is None and not src.lazy:
-                xs = getattr(src.x, "_x3", None)        # a raw operand (dy) packed earlier for the weight gradient
-            if xs is None:
-                xs = self.x3_pack(a.src, src.P, src.C, out.device)
-                src._x3 = xs
-                if not src.lazy:
-                    try:
-                        src.x._x3 = xs
-                    except AttributeError:
-                        pass
+            xs = self._packed(src, a.src, out.device)
             xw = getattr(w, "_x3", None)
             if xw is None:
                 xw = self.x3_pack_rows(w)
@@ -313,8 +303,28 @@ class HipKernels:
         self._ck(self.lib.uda_x3_pack(C.byref(usrc), out.data_ptr(), self._stream()))
         return out
 
-    def x3_pack_act(self, act: Act):
-        return self.x3_pack(self._src(act), act.P, act.C, act.x.device)
+    def _packed(self, src: Act, usrc: UdaSrc, device):
+        """The packed form of a conv operand, split once per step: it rides on the descriptor (a pending transform belongs to the
+        descriptor) and, for a raw operand (a gradient matrix, a discriminator's space-to-depth image), on the tensor object, so
+        the forward conv, the input-gradient conv and the weight gradient that read the same matrix share one packing pass.
+        The engines never write into a matrix after it has been read as a conv operand (gradients are complete before the
+        producer's backward reads them)."""
+        xs = getattr(src, "_x3", None)
+        raw = not src.lazy
+        if xs is None and raw:
+            xs = getattr(src.x, "_x3", None)
+        if xs is not None and xs.numel() != int(self.lib.uda_x3_packed_bytes(src.P, src.C)):
+            raise RuntimeError("bf16x3 packed operand of %d bytes attached to a [%d, %d] matrix (expected %d): stale attachment"
+                               % (xs.numel(), src.P, src.C, int(self.lib.uda_x3_packed_bytes(src.P, src.C))))
+        if xs is None:
+            xs = self.x3_pack(usrc, src.P, src.C, device)
+            if raw:
+                try:
+                    src.x._x3 = xs
+                except AttributeError:
+                    pass
+        src._x3 = xs
+        return xs
 
     def x3_pack_rows(self, w):
         """a relayouted weight [rows, taps, K'] (contiguous rows) as packed rows"""
@@ -349,17 +359,9 @@ class HipKernels:
         if self.mfma != self.MFMA_F32 and self.lib.uda_conv_wgrad_uses_x3(C.byref(a)):
             # bf16x3: the source's packed form usually exists already (the forward conv packed the same descriptor); dy is packed
             # once for its input-gradient conv and this weight gradient (the packed form rides on the tensor object)
-            xs = getattr(src, "_x3", None)
-            if xs is None:
-                xs = self.x3_pack(a.src, src.P, src.C, dy.device)
-                src._x3 = xs
-            xd = getattr(dy, "_x3", None)
-            if xd is None:
-                xd = self.x3_pack_act(Act(dy, src.N, src.H, src.W))
-                try:
-                    dy._x3 = xd
-                except AttributeError:
-                    pass
+            xs = self._packed(src, a.src, dy.device)
+            dsrc = Act(dy, src.N, src.H, src.W)
+            xd = self._packed(dsrc, self._src(dsrc), dy.device)
             a.x3_src, a.x3_dy = xs.data_ptr(), xd.data_ptr()
         self._ck(self.lib.uda_conv_wgrad(C.byref(a), self._stream()))
 

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     const int nchunks = a.nchunks;
     const int T = a.ksize * a.ksize;
 
-    // ------------------------------------------------------------------ loader state (global offsets in 16-byte units)
+    constexpr int OOB = 0x7ffffff0;                              // byte offset beyond every descriptor: loads return 0, stores are dropped
+    if (loader) {
+    // ------------------------------------------------------------------ loader waves: state (global offsets in 16-byte units), then the
+    // staging loop.  Everything of the loader lives inside this branch: state computed before it would stay live (spilled)
+    // across the math waves' path.
     const int lt = (tid - MW * 64) & 255;
     // unit u = lt + 256 * i -> (row = u / 6, part = u % 6); its LDS byte offset row * 112 + part * 16 = 16 * (u + row) is recomputed
     // per use, the nine tap-validity bits of three units share one register: the loader's two register sets (96 VGPRs at
@@ -159,7 +163,6 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     uint4 areg0[A_U], breg0[B_U], areg1[A_U], breg1[B_U];        // two chunks in flight (two register sets, statically indexed)
     int t_cur = 0, blk = 0, half = 0, chunk = 0;
     const int rowA16 = a.nbA * 6;                                // uint4 per packed activation row
-    if (loader) {
 #pragma unroll
         for (int i = 0; i < (A_U + 2) / 3; ++i) vmask3[i] = 0;
 #pragma unroll
@@ -191,13 +194,10 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             const int n = min(n0 + row, a.Cout - 1);
             boff[i] = n * (nchunks * 6) + part;
         }
-    }
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(a.xa), 0, (int)min((int64_t)0x7fffffff, P * rowA16 * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(a.xw), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.Cout * nchunks * 96), 0x00020000);
-    constexpr int OOB = 0x7ffffff0;
-
     auto issue = [&](uint4 (&ar)[A_U], uint4 (&br)[B_U]) {
         const int t = t_cur, b16 = blk + half;
         const bool kval = b16 < a.nbA;
@@ -242,15 +242,6 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             if (B_FULL || lt + 256 * i < B_UNITS) *reinterpret_cast<uint4*>(Bs + 16 * (lt + 256 * i + unit_row(lt + 256 * i))) = br[i];
     };
 
-    // ------------------------------------------------------------------ math state
-    const int wm = (wave / WNN) % WMM, wn = wave % WNN;
-    const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TNW) + (lane & 31);
-    const int koff = 8 * (lane >> 5);
-
-    float s1[TNW], s2[TNW];
-#pragma unroll
-    for (int j = 0; j < TNW; ++j) s1[j] = s2[j] = 0.f;
-    if (loader) {
         // chunk c lives in register set c & 1 and in LDS buffer c & 1; chunks c + 1 and c + 2 are in flight while chunk c is computed
         issue(areg0, breg0);
         if (nchunks > 1) issue(areg1, breg1);
@@ -272,6 +263,10 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             }
         }
     } else {
+        // -------------------------------------------------------------- math waves
+        const int wm = (wave / WNN) % WMM, wn = wave % WNN;
+        const int arow = wm * 64 + (lane & 31), brow = wn * (32 * TNW) + (lane & 31);
+        const int koff = 8 * (lane >> 5);
         f32x16 acc[TM][TNW];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -316,32 +311,45 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             __syncthreads();
         }
         __builtin_amdgcn_s_setprio(0);
-        // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Stores (and the addend's loads) go through
+        // buffer descriptors over this tile's rows: an element beyond the matrix (row or column) gets an out-of-range offset and
+        // is dropped by the hardware - no per-element branches, one offset register per lane
+        // (the per-element 64-bit addresses of plain stores cost ~20 spilled registers per math wave and their scratch traffic)
+        float s1[TNW], s2[TNW];
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) s1[j] = s2[j] = 0.f;
+        const int rows_left = (int)min((int64_t)BM, P - m0);
+        const int ldy4 = (int)a.ldy * 4, lda4 = (int)a.ld_add * 4;
+        const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+            a.y + m0 * a.ldy, 0, ((rows_left - 1) * (int)a.ldy + a.Cout) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t adres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.addend ? a.addend + m0 * a.ld_add : a.y), 0, a.addend ? ((rows_left - 1) * (int)a.ld_add + a.Cout) * 4 : 0, 0x00020000);
         const int colb = n0 + wn * (32 * TNW) + (lane & 31);
+        const int rbase = wm * 64 + 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
             const int col = colb + 32 * j;
             const bool cok = col < a.Cout;
             const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
+            const int voff = cok ? rbase * ldy4 + col * 4 : OOB, vadd = cok ? rbase * lda4 + col * 4 : OOB;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (cok && row < P) {
-                        float v = acc[i][j][r] + bv;
-                        s1[j] += v;
-                        s2[j] += v * v;
-                        if (a.addend) v += a.addend[row * a.ld_add + col];
-                        a.y[row * a.ldy + col] = v;
-                    }
+                    const int rl = 32 * i + (r & 3) + 8 * (r >> 2);          // row inside the wave's 64-row band (compile-time)
+                    float v = acc[i][j][r] + bv;
+                    const bool ok = cok && (rbase + rl) < rows_left;
+                    s1[j] += ok ? v : 0.f;
+                    s2[j] += ok ? v * v : 0.f;
+                    // (the per-lane offset itself goes out of range for a row beyond the matrix: the descriptor's range check is
+                    // not relied upon to include the scalar row offset)
+                    if (a.addend) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(adres, ok ? vadd : OOB, rl * lda4, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, ok ? voff : OOB, rl * ldy4, 0);
                 }
             }
         }
-    }
-    if (a.stats) {           // uniform over the workgroup
-        float* red = reinterpret_cast<float*>(smem16);   // [WMM][2][BN]
-        if (!loader) {
+        if (a.stats) {       // (every wave is past the last chunk's barrier: the staging buffers are free)
+            float* red = reinterpret_cast<float*>(smem16);   // [WMM][2][BN]
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
                 const float t1 = s1[j] + __shfl_xor(s1[j], 32);
@@ -353,6 +361,9 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
                 }
             }
         }
+    }
+    if (a.stats) {           // uniform over the workgroup
+        float* red = reinterpret_cast<float*>(smem16);   // [WMM][2][BN]
         __syncthreads();
         double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
         for (int e = tid; e < 2 * BN; e += NTHR) {
@@ -394,7 +405,7 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st) {
 // the 256 x 64 tile; 1x1 convs only when very wide (256 -> 2304 tap GEMM of the re-associated decoder conv: 1.6-1.8x; 1280 -> 256
 // at 16384 pixels: 1.0x, stays on the fp32 pipe).
 bool conv_x3_eligible(const ConvKArgs& k) {
-    if (k.ksize == 1) return k.Kc >= 128 && k.Cout >= 1024;
+    if (k.ksize == 1) return k.Kc >= 128 && k.Cout >= 1024;     // (measured with Cout >= 128: the backbone's 1x1 convs gain nothing, the packing pass eats it)
     return k.Kc >= IG_BK && k.Cout * k.ksize * k.ksize >= 432;
 }
 
@@ -485,14 +496,17 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
     const int64_t P = (int64_t)a.N * H * W;
     const int c0 = split * a.cps, c1 = min(a.nchunks, c0 + a.cps), n = c1 - c0;
 
-    // ------------------------------------------------------------------ loader state
+    constexpr int OOB = 0x7ffffff0;
+    if (loader) {
+    // ------------------------------------------------------------------ loader waves (all of their state inside this branch, as in
+    // the forward kernel)
     const int lt = (tid - MW * 64) & 255, ps = lt >> 4, li = lt & 15;
     int aoff[UA], boff[UB], btap[UB];                   // 16-byte unit offsets relative to the pixel row; packed (dh, dw) of the unit's tap
     unsigned aval = 0, bval = 0;                        // per-unit "block exists" bits
     uint4 ar0[UA], br0[UB], ar1[UA], br1[UB];
     int pcur = c0 * 16 + ps, hcur = 0, wcur = 0;
     const int rowDy = a.nbCo * 6, rowS = a.nbC * 6;
-    if (loader) {
+    {
         const int q = (int)(pcur < P ? pcur : 0);
         wcur = q % W;
         hcur = (q / W) % H;
@@ -523,8 +537,6 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
         const_cast<uint32_t*>(a.xdy), 0, (int)min((int64_t)0x7fffffff, P * rowDy * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(a.xs), 0, (int)min((int64_t)0x7fffffff, P * rowS * 16), 0x00020000);
-    constexpr int OOB = 0x7ffffff0;
-
     auto issue = [&](uint4 (&ar)[UA], uint4 (&br)[UB]) {
         const bool pin = pcur < (int)P;
 #pragma unroll
@@ -558,7 +570,6 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
         }
     };
 
-    if (loader) {
         if (n > 0) {
             issue(ar0, br0);
             if (n > 1) issue(ar1, br1);
@@ -626,18 +637,25 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
             __syncthreads();
         }
         __builtin_amdgcn_s_setprio(0);
-        float* slab = a.slab + (int64_t)split * a.Cout * a.Jtot;
+        // slab tile through a buffer descriptor: rows beyond Cout / columns beyond Jtot get an out-of-range offset (dropped)
+        float* slab = a.slab + ((int64_t)split * a.Cout + (int64_t)cot * BM) * a.Jtot;
+        const int rows_left = min(BM, a.Cout - cot * BM), J4 = a.Jtot * 4;
+        const __amdgpu_buffer_rsrc_t sres2 = __builtin_amdgcn_make_buffer_rsrc(slab, 0, rows_left * J4, 0x00020000);
+        const int rbase = wm * (BM / 4) + 4 * (lane >> 5);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            const int col = jt * BN + wn * (BN / 2) + 32 * j + (lane & 31);
+            const int voff = col < a.Jtot ? rbase * J4 + col * 4 : OOB;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = jt * BN + wn * (BN / 2) + 32 * j + (lane & 31);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = cot * BM + wm * (BM / 4) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < a.Cout && col < a.Jtot) slab[(int64_t)row * a.Jtot + col] = acc[i][j][r];
+                    const int rl = 32 * i + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[i][j][r];      // (a __builtin_bit_cast applied to the vector element itself reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), sres2,
+                                                          (rbase + rl) < rows_left ? voff : OOB, rl * J4, 0);
                 }
-            }
+        }
     }
 }
 

@@ -345,6 +345,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    peak_gib = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -437,6 +438,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.use_tn:
             line["cpu_baseline"] = cpu_baseline(args.workload, 2, args.size, args.backbone)
         line["other_mfma"] = other
+        line["peak_hbm_gib"] = round(peak_gib, 2)          # torch allocator peak of this rank up to the end of the timed region (of 288)
         line["host_input"] = host
         print(json.dumps(line), flush=True)
     if dist is not None:

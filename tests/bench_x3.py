@@ -29,7 +29,12 @@ cases = [("decoder conv4 fwd masked B=16", 16, 128, 128, 256, 256, 3, 1, True, T
          ("decoder conv4 fwd masked B=32 (MC batch)", 32, 128, 128, 256, 256, 3, 1, True, True),
          ("conv4 dgrad raw B=16", 16, 128, 128, 256, 256, 3, 1, False, False),
          ("ASPP atrous d=6 B=16", 16, 32, 32, 320, 256, 3, 6, True, False),
+         ("disc L2 fwd 2x2 64->128 (z 256) B=16", 16, 131, 131, 256, 128, 2, 1, False, False),
+         ("disc L2 dgrad 2x2 (dy 128 -> z 256) B=16", 16, 131, 131, 128, 256, 2, 1, False, False),
          ("disc L3 2x2 128->256 B=16", 16, 67, 67, 512, 256, 2, 1, False, False),
+         ("disc L3 dgrad 2x2 (dy 256 -> z 512) B=16", 16, 67, 67, 256, 512, 2, 1, False, False),
+         ("disc L4 fwd 2x2 (z 1024 -> 512) B=16", 16, 35, 35, 1024, 512, 2, 1, False, False),
+         ("disc L4 dgrad 2x2 (dy 512 -> z 1024) B=16", 16, 35, 35, 512, 1024, 2, 1, False, False),
          ("1x1 1280->256 B=16", 16, 32, 32, 1280, 256, 1, 1, True, False),
          ("1x1 tap GEMM 256->2304 B=32", 32, 32, 32, 256, 2304, 1, 1, False, False),
          ("1x1 tap GEMM 256->2304 B=16", 16, 32, 32, 256, 2304, 1, 1, False, False)]

@@ -444,19 +444,42 @@ int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w
     x.N = k.src.N; x.H = k.src.H; x.W = k.src.W; x.nbA = nbA;
     x.Cout = k.Cout; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen; x.nchunks = nch;
     x.bias = k.bias; x.addend = k.addend; x.ld_add = k.ld_add; x.y = k.y; x.ldy = k.ldy; x.stats = k.stats;
-    // 256 x 256 tiles once they fill the chip twice over; 128 x 256 for wide outputs on fewer pixels; 128 x 128 otherwise
-    const bool wide = k.Cout > 128;
-    const bool tall = wide && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
-    const bool mid = wide && uda_cdiv(P, 128) * uda_cdiv(k.Cout, 256) >= 256;
-    if (k.ksize >= 2) {
-        if (k.Cout <= 64) return launch_x3<3, 1, 256>(x, P, st);      // input gradient towards a narrow tensor (decoder low-level branch)
-        if (tall) return launch_x3<3, 4, 256>(x, P, st);
-        if (mid) return launch_x3<3, 4, 128>(x, P, st);
-        return launch_x3<3, 2, 128>(x, P, st);
+    if (k.ksize >= 2 && k.Cout <= 64) return launch_x3<3, 1, 256>(x, P, st);      // input gradient towards a narrow tensor (decoder low-level branch)
+    // Tile choice: the cheapest of 256 x 256, 128 x 256, 256 x 128, 128 x 128 under  rounds x tile area / tile efficiency, a round
+    // being one tile per CU - padding waste (Cout = 304 fits three 128-wide tiles better than two 256-wide ones) and the partly
+    // filled last round both count.  Efficiencies fitted to the discriminator layers (tests/bench_x3.py with UDA_X3_TILE forcing
+    // a tile; the tiles stage 32 / 48 / 48 / 64 B per MFMA clock and CU, two 128 x 128 workgroups can share a CU).
+    static const int force = getenv("UDA_X3_TILE") ? atoi(getenv("UDA_X3_TILE")) : -1;
+    const int bm[4] = {256, 128, 256, 128}, bn[4] = {256, 256, 128, 128};
+    const double eff[4] = {1.0, 0.97, 0.92, 0.84};
+    int best = 0;
+    double bestc = 1e300;
+    for (int t = 0; t < 4; ++t) {
+        const int64_t tiles = uda_cdiv(P, bm[t]) * uda_cdiv(k.Cout, bn[t]);
+        const double c = (double)uda_cdiv(tiles, 256) * bm[t] * bn[t] / eff[t];
+        if (c < bestc) { bestc = c; best = t; }
     }
-    if (tall) return launch_x3<1, 4, 256>(x, P, st);
-    if (mid) return launch_x3<1, 4, 128>(x, P, st);
-    return launch_x3<1, 2, 128>(x, P, st);
+    if (force >= 0 && force < 4) best = force;
+    if (force == -2) {      // (A/B: the fixed thresholds used before the cost model)
+        const bool wide = k.Cout > 128;
+        const bool tall = wide && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
+        const bool mid = wide && uda_cdiv(P, 128) * uda_cdiv(k.Cout, 256) >= 256;
+        best = tall ? 0 : (mid ? 1 : 3);
+    }
+    if (k.ksize >= 2) {
+        switch (best) {
+            case 0: return launch_x3<3, 4, 256>(x, P, st);
+            case 1: return launch_x3<3, 4, 128>(x, P, st);
+            case 2: return launch_x3<3, 2, 256>(x, P, st);
+            default: return launch_x3<3, 2, 128>(x, P, st);
+        }
+    }
+    switch (best) {
+        case 0: return launch_x3<1, 4, 256>(x, P, st);
+        case 1: return launch_x3<1, 4, 128>(x, P, st);
+        case 2: return launch_x3<1, 2, 256>(x, P, st);
+        default: return launch_x3<1, 2, 128>(x, P, st);
+    }
 }
 
 // ==========================================================================================================================

@@ -92,9 +92,13 @@ typedef struct uda_conv_args {
     int32_t _pad3;
     const void* x3_src;    /* UDA_MFMA_BF16X3, when uda_conv_uses_x3(a): src packed by uda_x3_pack (transform already applied) ... */
     const void* x3_w;      /* ... and the weight rows w ([Cout] rows of the relayouted row length) packed by uda_x3_pack */
+    void* workspace;       /* optional, 16-byte aligned: uda_conv_fwd_workspace_bytes(a) bytes let the bf16x3 kernel split the last, */
+    uint64_t workspace_bytes; /* partly filled round of tiles over K (fp32 partial tiles, summed in a fixed order); NULL / too small: not split */
 } uda_conv_args_t;
 /* 1 when uda_conv_fwd will run these arguments on the bf16x3 wide-tile kernel and therefore needs x3_src / x3_w */
 int uda_conv_uses_x3(const uda_conv_args_t* a);
+/* bytes of workspace these arguments can make use of (0: none; the conv runs the same without it) */
+uint64_t uda_conv_fwd_workspace_bytes(const uda_conv_args_t* a);
 int uda_conv_fwd(const uda_conv_args_t* a, void* stream);
 /* Operand packing for UDA_MFMA_BF16X3: every fp32 value as its three bf16 pieces, out[rows][ceil(C/16)][3][16] (96 contiguous
  * bytes per row and 16-wide block), rows = N*H*W of src, values = the TRANSFORMED ones act(x*scale+shift)*mask*mask_scale, so a

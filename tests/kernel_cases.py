@@ -804,6 +804,13 @@ CASES += [
     ("wgrad1x1 256->2304 P=4608 (x3, tap GEMM of the re-associated decoder conv)", case_wgrad(2, 48, 48, 256, 2304, 1, 1, lazy=False)),
     ("wgrad2x2 o0 1024->512 P=9248 (x3 256 tiles on few pixels)", case_wgrad(2, 68, 68, 1024, 512, 2, 1, lazy=False, origin=0)),
 ]
+# bf16x3: the last, partly filled round of tiles split over K (no statistics epilogue; fp32 partial tiles + x3_tail_reduce_kernel)
+CASES += [
+    ("conv3x3 64->128 P=37965 bias addend, no stats (x3 tail split, ragged rows)", case_conv(1, 195, 195 - 0, 64, 128, 3, 1, bias=True, addend=True, stats=False)),
+    ("conv2x2 o1 256->250 P=38000 raw, no stats (x3 tail split, ragged columns)", case_conv(1, 200, 190, 256, 250, 2, 1, lazy=False, stats=False, origin=1)),
+    ("conv1x1 256->2304 P=4864 no stats (x3 tail split, wide 1x1)", case_conv(1, 38, 128, 256, 2304, 1, 1, lazy=False, stats=False)),
+    ("dgrad3x3 304<-256 P=37888 accumulate (x3 tail split)", case_dgrad(2, 148, 128, 304, 256, 3, 1, accumulate=True)),
+]
 # bf16x3 routes added with the 256 x 64 tile and the wide 1x1 route
 CASES += [
     ("conv1x1 256->2304 stats (x3 wide 1x1)", case_conv(2, 40, 36, 256, 2304, 1, 1, lazy=False)),

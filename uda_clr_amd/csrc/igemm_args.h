@@ -39,4 +39,5 @@ int launch_wgrad_ws(WgradKArgs& k, int S, bool big, hipStream_t st);  // 128 x 1
 bool conv_x3_eligible(const ConvKArgs& k);
 bool wgrad_x3_eligible(int Cin, int Cout, int ksize, int64_t P);
 int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_src, const void* x3_dy, hipStream_t st, int& S_out);   // bf16x3 weight gradient
-int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st);   // bf16x3 forward / dgrad (igemm_x3.hip)
+int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st, void* ws, uint64_t ws_bytes);
+uint64_t conv_x3_workspace_bytes(const ConvKArgs& k, int64_t P);      // bytes the tail split of this conv wants (0: none)   // bf16x3 forward / dgrad (igemm_x3.hip)

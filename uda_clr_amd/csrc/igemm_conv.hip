@@ -451,6 +451,15 @@ extern "C" int uda_conv_uses_x3(const uda_conv_args_t* a) {
     return conv_is_wide(a, Kc, Ktot) && conv_x3_eligible(k) ? 1 : 0;
 }
 
+extern "C" uint64_t uda_conv_fwd_workspace_bytes(const uda_conv_args_t* a) {
+    if (!uda_conv_uses_x3(a)) return 0;
+    ConvKArgs k;
+    k.src = a->src; k.Cout = a->Cout; k.ksize = a->ksize; k.stats = a->stats;
+    k.Kc = ((a->src.C + 3) / 4) * 4;
+    k.Ktot = uda_k_row(a->src.C, a->ksize);
+    return conv_x3_workspace_bytes(k, (int64_t)a->src.N * a->src.H * a->src.W);
+}
+
 extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(a != nullptr, "uda_conv_fwd: null args");
@@ -493,7 +502,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
         UDA_LAUNCH_CHECK("conv_heads");
         return 0;
     }
-    if (uda_conv_uses_x3(a)) e = launch_conv_x3(k, P, a->x3_src, a->x3_w, st);
+    if (uda_conv_uses_x3(a)) e = launch_conv_x3(k, P, a->x3_src, a->x3_w, st, a->workspace, a->workspace_bytes);
     else if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);
@@ -505,7 +514,7 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
         else if (w128 <= w96) e = launch_conv<2, 2, 2, 2>(k, P, st);
         else e = launch_conv<1, 3, 4, 1>(k, P, st);
     }
-    else e = (k.x3 && conv_x3_eligible(k)) ? launch_conv_x3(k, P, a->x3_src, a->x3_w, st) : launch_conv_ws(k, P, st);
+    else e = (k.x3 && conv_x3_eligible(k)) ? launch_conv_x3(k, P, a->x3_src, a->x3_w, st, a->workspace, a->workspace_bytes) : launch_conv_ws(k, P, st);
     return e;
 }
 

@@ -123,9 +123,14 @@ struct X3KArgs {
     double* stats;
     int nMt, nNt;
     int debug;            // diagnostics (UDA_X3_DEBUG): bit0 skip the MFMAs, bit1 skip the loader's global loads, bit2 skip its LDS writes
+    // tail launch (launch_x3): this grid covers the tiles [tile_off, tile_off + gridDim.x / ksplit), each by ksplit workgroups that
+    // take consecutive ranges of the K chunks and write their fp32 partial tile to partial[blockIdx.x][BM][BN] (x3_tail_reduce_kernel
+    // sums them into y); ksplit = 1 / partial = nullptr: the ordinary launch over tiles [0, ntiles_main)
+    int tile_off, ksplit, ntiles_main;
+    float* partial;
 };
 
-template <int KS, int TN, int BM>
+template <int KS, int TN, int BM, bool TAIL = false>      // TAIL: the K-split tail launch (fp32 partial tiles, see X3KArgs)
 __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     constexpr int MW = 8, BN = 64 * TN, TM = 2;
     constexpr int WMM = BM / 64, WNN = MW / WMM, TNW = 2 * TN / WNN;
@@ -139,14 +144,17 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = __builtin_amdgcn_readfirstlane(wave) >= MW;
-    const int lid = uda_xcd_remap(blockIdx.x, a.nMt * a.nNt);
+    const int lid = TAIL ? a.tile_off + (int)blockIdx.x / a.ksplit : uda_xcd_remap(blockIdx.x, a.ntiles_main);
     const int mt = lid / a.nNt, nt = lid % a.nNt;
     const int H = a.H, W = a.W;
     const int64_t P = (int64_t)a.N * H * W;
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
-    const int nchunks = a.nchunks;
     const int T = a.ksize * a.ksize;
+    // K chunks of this workgroup: all of them, or the ks-th of ksplit consecutive ranges (tail launch)
+    const int ks = TAIL ? (int)blockIdx.x % a.ksplit : 0;
+    const int cper = TAIL ? (a.nchunks + a.ksplit - 1) / a.ksplit : a.nchunks, cbeg = ks * cper;
+    const int nchunks = TAIL ? max(0, min(a.nchunks, cbeg + cper) - cbeg) : a.nchunks;
 
     constexpr int OOB = 0x7ffffff0;                              // byte offset beyond every descriptor: loads return 0, stores are dropped
     if (loader) {
@@ -161,7 +169,13 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     int aoff[A_U], boff[B_U];
     unsigned vmask3[(A_U + 2) / 3];
     uint4 areg0[A_U], breg0[B_U], areg1[A_U], breg1[B_U];        // two chunks in flight (two register sets, statically indexed)
-    int t_cur = 0, blk = 0, half = 0, chunk = 0;
+    int t_cur = 0, blk = cbeg, half = 0, chunk = cbeg;           // KS == 1: one chunk per 16-channel block
+    if (KS == 3 && TAIL) {                                       // chunk c = ((pair * 2 + half) * T + t), pair = 32-channel slice
+        const int pair = cbeg / (2 * T), r = cbeg - pair * 2 * T;
+        half = r / T;
+        t_cur = r - half * T;
+        blk = 2 * pair;
+    }
     const int rowA16 = a.nbA * 6;                                // uint4 per packed activation row
 #pragma unroll
         for (int i = 0; i < (A_U + 2) / 3; ++i) vmask3[i] = 0;
@@ -192,12 +206,12 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
         for (int i = 0; i < B_U; ++i) {
             const int u = min(lt + 256 * i, B_UNITS - 1), row = unit_row(u), part = u - row * 6;
             const int n = min(n0 + row, a.Cout - 1);
-            boff[i] = n * (nchunks * 6) + part;
+            boff[i] = n * (a.nchunks * 6) + part;
         }
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(a.xa), 0, (int)min((int64_t)0x7fffffff, P * rowA16 * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(a.xw), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.Cout * nchunks * 96), 0x00020000);
+        const_cast<uint32_t*>(a.xw), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.Cout * a.nchunks * 96), 0x00020000);
     auto issue = [&](uint4 (&ar)[A_U], uint4 (&br)[B_U]) {
         const int t = t_cur, b16 = blk + half;
         const bool kval = b16 < a.nbA;
@@ -218,12 +232,7 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wres, (boff[i] + woff) * 16, 0, 0));
         ++chunk;
         if (KS == 3) {
-            if (a.debug & 8) {  // (old order, diagnostics) halves of a 32-channel slice share the tap; then the next tap
-                if ((half ^= 1) == 0 && ++t_cur == T) {
-                    t_cur = 0;
-                    blk += 2;
-                }
-            } else if (++t_cur == T) {      // all taps of one 16-channel block (its pixels stay in L2 for the T re-reads), then the next
+            if (++t_cur == T) {             // all taps of one 16-channel block (its pixels stay in L2 for the T re-reads), then the next
                 t_cur = 0;
                 if ((half ^= 1) == 0) blk += 2;
             }
@@ -243,10 +252,12 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     };
 
         // chunk c lives in register set c & 1 and in LDS buffer c & 1; chunks c + 1 and c + 2 are in flight while chunk c is computed
-        issue(areg0, breg0);
-        if (nchunks > 1) issue(areg1, breg1);
-        stage(areg0, breg0, smem16);
-        if (nchunks > 2) issue(areg0, breg0);
+        if (nchunks > 0) {
+            issue(areg0, breg0);
+            if (nchunks > 1) issue(areg1, breg1);
+            stage(areg0, breg0, smem16);
+            if (nchunks > 2) issue(areg0, breg0);
+        }
         __syncthreads();
         for (int c = 0; c < nchunks; c += 2) {
             if (c + 1 < nchunks) {
@@ -315,6 +326,23 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
         // buffer descriptors over this tile's rows: an element beyond the matrix (row or column) gets an out-of-range offset and
         // is dropped by the hardware - no per-element branches, one offset register per lane
         // (the per-element 64-bit addresses of plain stores cost ~20 spilled registers per math wave and their scratch traffic)
+        if constexpr (TAIL) {          // tail launch: the dense fp32 partial tile of this K range (bias, addend and bounds are the reduce kernel's)
+            const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(
+                a.partial + (int64_t)blockIdx.x * (BM * BN), 0, BM * BN * 4, 0x00020000);
+            const int pv = ((wm * 64 + 4 * (lane >> 5)) * BN + wn * (32 * TNW) + (lane & 31)) * 4;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), pres, pv + 128 * j,
+                                                              (32 * i + (r & 3) + 8 * (r >> 2)) * (BN * 4), 0);
+                    }
+            return;
+        }
+        if constexpr (TAIL) return;    // (unreachable; keeps the ordinary epilogue out of the tail instantiation)
         float s1[TNW], s2[TNW];
 #pragma unroll
         for (int j = 0; j < TNW; ++j) s1[j] = s2[j] = 0.f;
@@ -362,7 +390,7 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             }
         }
     }
-    if (a.stats) {           // uniform over the workgroup
+    if (!TAIL && a.stats) {  // uniform over the workgroup
         float* red = reinterpret_cast<float*>(smem16);   // [WMM][2][BN]
         __syncthreads();
         double* dst = a.stats + (int64_t)(mt % UDA_STAT_SLOTS) * 2 * a.Cout;
@@ -378,8 +406,71 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     }
 }
 
+// Sum of the tail launch's partial tiles into y (+ bias, + addend), fixed order: bitwise reproducible.
+struct X3TailArgs {
+    const float* partial;     // [ntail * ksplit][BM][BN]
+    int ksplit, tile_off, ntail, nNt, BM, BN, Cout;
+    int64_t P;
+    const float* bias;
+    const float* addend;
+    int64_t ld_add;
+    float* y;
+    int64_t ldy;
+};
+
+__global__ __launch_bounds__(256) void x3_tail_reduce_kernel(X3TailArgs a) {
+    const int bn4 = a.BN >> 2, per_tile = a.BM * bn4;
+    const int64_t total = (int64_t)a.ntail * per_tile;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int tl = (int)(e / per_tile), q = (int)(e - (int64_t)tl * per_tile), r = q / bn4, c4 = (q - r * bn4) * 4;
+        const int lid = a.tile_off + tl, mt = lid / a.nNt, nt = lid - mt * a.nNt;
+        const int64_t row = (int64_t)mt * a.BM + r;
+        const int col = nt * a.BN + c4;
+        if (row >= a.P || col >= a.Cout) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < a.ksplit; ++s) {
+            const float4 v = uda_ld4(a.partial + (((int64_t)tl * a.ksplit + s) * a.BM + r) * a.BN + c4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (col + jj < a.Cout) {
+                float v = o[jj] + (a.bias ? a.bias[col + jj] : 0.f);
+                if (a.addend) v += a.addend[row * a.ld_add + col + jj];
+                a.y[row * a.ldy + col + jj] = v;
+            }
+    }
+}
+
+// Tail plan of a tile choice: the last, partly filled round of tiles is computed by ksplit workgroups per tile over consecutive K
+// ranges (x3_tail_reduce_kernel sums the partial tiles) when the conv has no statistics epilogue and the caller gave a workspace.
+struct X3Tail {
+    int64_t tiles, full, tail;
+    int ksplit;
+};
+
+static X3Tail x3_tail_plan(int64_t P, int Cout, int nchunks, int BM, int BN, bool allow) {
+    X3Tail t;
+    t.tiles = uda_cdiv(P, BM) * uda_cdiv(Cout, BN);
+    t.full = (t.tiles / 256) * 256;
+    t.tail = t.tiles - t.full;
+    t.ksplit = 1;
+    if (allow && t.tail > 0 && t.tail <= 128) {
+        int s = (int)(256 / t.tail);
+        if (s > 8) s = 8;
+        if (s > nchunks / 8) s = nchunks / 8;       // at least 8 chunks per workgroup
+        if (s >= 2) t.ksplit = s;
+    }
+    return t;
+}
+
+static uint64_t x3_tail_bytes(const X3Tail& t, int BM, int BN) {
+    return t.ksplit > 1 ? (uint64_t)t.tail * t.ksplit * BM * BN * sizeof(float) : 0;
+}
+
 template <int KS, int TN, int BM>
-static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st) {
+static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, uint64_t ws_bytes = 0) {
     constexpr int BN = 64 * TN;
     constexpr size_t lds = 2 * (BM + BN) * X3_ROW * sizeof(__bf16);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
@@ -394,8 +485,32 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st) {
     k.nNt = uda_cdiv(k.Cout, BN);
     static const int dbg = getenv("UDA_X3_DEBUG") ? atoi(getenv("UDA_X3_DEBUG")) : 0;
     k.debug = dbg;
-    hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3(768), lds, st, k);
-    UDA_LAUNCH_CHECK("igemm_conv_x3");
+    X3Tail t = x3_tail_plan(P, k.Cout, k.nchunks, BM, BN, k.stats == nullptr && ws != nullptr);
+    if (x3_tail_bytes(t, BM, BN) > ws_bytes) t.ksplit = 1;
+    k.tile_off = 0; k.ksplit = 1; k.partial = nullptr;
+    k.ntiles_main = (int)(t.ksplit > 1 ? t.full : t.tiles);
+    if (k.ntiles_main > 0) {
+        hipLaunchKernelGGL(fn, dim3(k.ntiles_main), dim3(768), lds, st, k);
+        UDA_LAUNCH_CHECK("igemm_conv_x3");
+    }
+    if (t.ksplit > 1) {
+        k.tile_off = (int)t.full; k.ksplit = t.ksplit; k.partial = reinterpret_cast<float*>(ws);
+        static bool configured_tail = false;
+        auto fnt = igemm_conv_x3_kernel<KS, TN, BM, true>;
+        if (!configured_tail) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fnt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return uda_set_error("igemm_conv_x3 (tail): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            configured_tail = true;
+        }
+        hipLaunchKernelGGL(fnt, dim3((int)t.tail * t.ksplit), dim3(768), lds, st, k);
+        UDA_LAUNCH_CHECK("igemm_conv_x3 (tail)");
+        X3TailArgs r;
+        r.partial = k.partial; r.ksplit = t.ksplit; r.tile_off = (int)t.full; r.ntail = (int)t.tail; r.nNt = k.nNt; r.BM = BM; r.BN = BN;
+        r.Cout = k.Cout; r.P = P; r.bias = k.bias; r.addend = k.addend; r.ld_add = k.ld_add; r.y = k.y; r.ldy = k.ldy;
+        const int64_t work = (int64_t)t.tail * BM * (BN / 4);
+        hipLaunchKernelGGL(x3_tail_reduce_kernel, dim3((int)uda_cdiv(work, 256)), dim3(256), 0, st, r);
+        UDA_LAUNCH_CHECK("x3_tail_reduce");
+    }
     return 0;
 }
 
@@ -432,7 +547,40 @@ extern "C" int uda_x3_pack(const uda_src_t* src, void* out, void* stream) {
     return 0;
 }
 
-int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st) {
+// Tile choice: the cheapest of 256 x 256, 128 x 256, 256 x 128, 128 x 128 under  rounds x tile area / tile efficiency, a round
+// being one tile per CU - padding waste (Cout = 304 fits three 128-wide tiles better than two 256-wide ones) and the partly
+// filled last round both count; with a workspace and no statistics epilogue that last round is split over K (x3_tail_plan) and
+// costs 1 / ksplit of a round plus the reduce.  Efficiencies fitted to the discriminator layers (tests/bench_x3.py with
+// UDA_X3_TILE forcing a tile; the tiles stage 32 / 48 / 48 / 64 B per MFMA clock and CU, two 128 x 128 workgroups can share a CU).
+static int x3_pick_tile(int64_t P, int Cout, int nchunks, bool allow_tail) {
+    static const int force = getenv("UDA_X3_TILE") ? atoi(getenv("UDA_X3_TILE")) : -1;
+    if (force >= 0 && force < 4) return force;
+    const int bm[4] = {256, 128, 256, 128}, bn[4] = {256, 256, 128, 128};
+    const double eff[4] = {1.0, 0.97, 0.92, 0.84};
+    int best = 0;
+    double bestc = 1e300;
+    for (int t = 0; t < 4; ++t) {
+        const X3Tail tp = x3_tail_plan(P, Cout, nchunks, bm[t], bn[t], allow_tail);
+        double rounds = (double)(tp.full / 256);
+        if (tp.tail > 0) rounds += tp.ksplit > 1 ? 1.0 / tp.ksplit + 0.12 : 1.0;
+        const double c = rounds * bm[t] * bn[t] / eff[t];
+        if (c < bestc) { bestc = c; best = t; }
+    }
+    return best;
+}
+
+static const int X3_TILE_BM[4] = {256, 128, 256, 128}, X3_TILE_BN[4] = {256, 256, 128, 128};
+
+// workspace the tail split of this conv wants (0: none)
+uint64_t conv_x3_workspace_bytes(const ConvKArgs& k, int64_t P) {
+    static const bool off = getenv("UDA_X3_NO_TAIL") != nullptr;
+    if (off || k.stats || (k.ksize >= 2 && k.Cout <= 64)) return 0;
+    const int nch = uda_cdiv(k.Ktot, X3_BK);
+    const int t = x3_pick_tile(P, k.Cout, nch, true);
+    return x3_tail_bytes(x3_tail_plan(P, k.Cout, nch, X3_TILE_BM[t], X3_TILE_BN[t], true), X3_TILE_BM[t], X3_TILE_BN[t]);
+}
+
+int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st, void* ws, uint64_t ws_bytes) {
     const int64_t lim = (int64_t)1 << 31;
     const int nbA = x3_nb(k.src.C), nch = uda_cdiv(k.Ktot, X3_BK);
     UDA_REQUIRE(x3_src && x3_w && uda_aligned16(x3_src) && uda_aligned16(x3_w),
@@ -445,40 +593,23 @@ int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w
     x.Cout = k.Cout; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen; x.nchunks = nch;
     x.bias = k.bias; x.addend = k.addend; x.ld_add = k.ld_add; x.y = k.y; x.ldy = k.ldy; x.stats = k.stats;
     if (k.ksize >= 2 && k.Cout <= 64) return launch_x3<3, 1, 256>(x, P, st);      // input gradient towards a narrow tensor (decoder low-level branch)
-    // Tile choice: the cheapest of 256 x 256, 128 x 256, 256 x 128, 128 x 128 under  rounds x tile area / tile efficiency, a round
-    // being one tile per CU - padding waste (Cout = 304 fits three 128-wide tiles better than two 256-wide ones) and the partly
-    // filled last round both count.  Efficiencies fitted to the discriminator layers (tests/bench_x3.py with UDA_X3_TILE forcing
-    // a tile; the tiles stage 32 / 48 / 48 / 64 B per MFMA clock and CU, two 128 x 128 workgroups can share a CU).
-    static const int force = getenv("UDA_X3_TILE") ? atoi(getenv("UDA_X3_TILE")) : -1;
-    const int bm[4] = {256, 128, 256, 128}, bn[4] = {256, 256, 128, 128};
-    const double eff[4] = {1.0, 0.97, 0.92, 0.84};
-    int best = 0;
-    double bestc = 1e300;
-    for (int t = 0; t < 4; ++t) {
-        const int64_t tiles = uda_cdiv(P, bm[t]) * uda_cdiv(k.Cout, bn[t]);
-        const double c = (double)uda_cdiv(tiles, 256) * bm[t] * bn[t] / eff[t];
-        if (c < bestc) { bestc = c; best = t; }
-    }
-    if (force >= 0 && force < 4) best = force;
-    if (force == -2) {      // (A/B: the fixed thresholds used before the cost model)
-        const bool wide = k.Cout > 128;
-        const bool tall = wide && uda_cdiv(P, 256) * uda_cdiv(k.Cout, 256) >= 512;
-        const bool mid = wide && uda_cdiv(P, 128) * uda_cdiv(k.Cout, 256) >= 256;
-        best = tall ? 0 : (mid ? 1 : 3);
-    }
+    const uint64_t want = conv_x3_workspace_bytes(k, P);
+    const bool tail_ok = want > 0 && ws != nullptr && ws_bytes >= want && uda_aligned16(ws);
+    if (!tail_ok) { ws = nullptr; ws_bytes = 0; }
+    const int best = x3_pick_tile(P, k.Cout, nch, tail_ok);
     if (k.ksize >= 2) {
         switch (best) {
-            case 0: return launch_x3<3, 4, 256>(x, P, st);
-            case 1: return launch_x3<3, 4, 128>(x, P, st);
-            case 2: return launch_x3<3, 2, 256>(x, P, st);
-            default: return launch_x3<3, 2, 128>(x, P, st);
+            case 0: return launch_x3<3, 4, 256>(x, P, st, ws, ws_bytes);
+            case 1: return launch_x3<3, 4, 128>(x, P, st, ws, ws_bytes);
+            case 2: return launch_x3<3, 2, 256>(x, P, st, ws, ws_bytes);
+            default: return launch_x3<3, 2, 128>(x, P, st, ws, ws_bytes);
         }
     }
     switch (best) {
-        case 0: return launch_x3<1, 4, 256>(x, P, st);
-        case 1: return launch_x3<1, 4, 128>(x, P, st);
-        case 2: return launch_x3<1, 2, 256>(x, P, st);
-        default: return launch_x3<1, 2, 128>(x, P, st);
+        case 0: return launch_x3<1, 4, 256>(x, P, st, ws, ws_bytes);
+        case 1: return launch_x3<1, 4, 128>(x, P, st, ws, ws_bytes);
+        case 2: return launch_x3<1, 2, 256>(x, P, st, ws, ws_bytes);
+        default: return launch_x3<1, 2, 128>(x, P, st, ws, ws_bytes);
     }
 }
 

@@ -31,7 +31,8 @@ class UdaConvArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("w", C.c_void_p), ("Cout", C.c_int32), ("ksize", C.c_int32),
                 ("dil", C.c_int32), ("origin", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
                 ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p),
-                ("mfma", C.c_int32), ("_pad3", C.c_int32), ("x3_src", C.c_void_p), ("x3_w", C.c_void_p)]
+                ("mfma", C.c_int32), ("_pad3", C.c_int32), ("x3_src", C.c_void_p), ("x3_w", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
 class UdaWgradArgs(C.Structure):
@@ -51,6 +52,7 @@ SYMBOLS = {
     "uda_relayout_dw": (_I, [_P, _I, _P, _P]),
     "uda_conv_fwd": (_I, [C.POINTER(UdaConvArgs), _P]),
     "uda_conv_uses_x3": (_I, [C.POINTER(UdaConvArgs)]),
+    "uda_conv_fwd_workspace_bytes": (_U, [C.POINTER(UdaConvArgs)]),
     "uda_x3_packed_bytes": (_U, [_L, _I]),
     "uda_x3_pack": (_I, [C.POINTER(UdaSrc), _P, _P]),
     "uda_conv_wgrad_workspace_bytes": (_U, [_L, _I, _I, _I]),
@@ -291,6 +293,10 @@ class HipKernels:
                 xw = self.x3_pack_rows(w)
                 w._x3 = xw
             a.x3_src, a.x3_w = xs.data_ptr(), xw.data_ptr()
+            nws = int(self.lib.uda_conv_fwd_workspace_bytes(C.byref(a)))
+            if nws:         # fp32 partial tiles of the K-split last round of tiles
+                ws = self._ws(out, nws)
+                a.workspace, a.workspace_bytes = ws.data_ptr(), nws
             return self._conv_x3(a)
         self._ck(self.lib.uda_conv_fwd(C.byref(a), self._stream()))
 

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(X3PackArgs a) {
     const int C = a.src.C, no = a.nb * 2, tid = threadIdx.x;     // octets per row
     const int64_t total = a.P * no, ntiles = (total + 255) >> 8;
     const float alo = a.src.act == ACT_NONE ? -INFINITY : 0.f, ahi = a.src.act == ACT_RELU6 ? 6.f : INFINITY;
+    const bool coef16 = ((reinterpret_cast<uintptr_t>(a.src.scale) | reinterpret_cast<uintptr_t>(a.src.shift)) & 15) == 0;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t e0 = tile << 8, p0 = e0 / no;
         const int oo = (int)(e0 - p0 * no) + tid, dp = oo / no, o = oo - dp * no;
@@ -81,10 +82,30 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(X3PackArgs a) {
                 if (XF >= 1) {
                     uint32_t mk = 0x01010101u;
                     if (XF == 2 && c < C) mk = *reinterpret_cast<const uint32_t*>(a.src.mask + p * a.src.ldm + c);
+                    // per-channel coefficients: one 16-byte load each where the four channels exist and the arrays are aligned (every
+                    // operand of the engine), scalar loads on a ragged last granule - the loads, not the bytes, set this kernel's rate
+                    float scv[4] = {1.f, 1.f, 1.f, 1.f}, shv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.src.scale) {
+                        if (c + 4 <= C && coef16) {
+                            const float4 q = uda_ld4(a.src.scale + c);
+                            scv[0] = q.x; scv[1] = q.y; scv[2] = q.z; scv[3] = q.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) if (c + j < C) scv[j] = a.src.scale[c + j];
+                        }
+                    }
+                    if (a.src.shift) {
+                        if (c + 4 <= C && coef16) {
+                            const float4 q = uda_ld4(a.src.shift + c);
+                            shv[0] = q.x; shv[1] = q.y; shv[2] = q.z; shv[3] = q.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) if (c + j < C) shv[j] = a.src.shift[c + j];
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bool ok = (c + j) < C;
-                        const float sc = (ok && a.src.scale) ? a.src.scale[c + j] : 1.f, sh = (ok && a.src.shift) ? a.src.shift[c + j] : 0.f;
+                        const float sc = scv[j], sh = shv[j];
                         float u = __builtin_amdgcn_fmed3f(t[j] * sc + sh, alo, ahi);
                         if (XF == 2) u *= ((mk >> (8 * j)) & 0xffu) ? a.src.mask_scale : 0.f;
                         t[j] = u;

@@ -226,7 +226,9 @@ extern "C" int uda_broadcast_rows(const float* g, int64_t ldg, int N, int HW, in
 }
 
 // ------------------------------------------------------------------------------------------
-// Philox4x32-10: one counter -> 16 keep bytes (4 x 32 random bits, one byte-wide compare each).
+// Philox4x32-10: one counter -> 8 keep bytes (4 x 32 random bits, one 16-bit compare each: the keep probability is exact to
+// 2^-17, i.e. 6e-6 at p = 0.1 and exact at p = 0.5).  The generator, not the store, sets this kernel's rate (10 rounds of two
+// 32 x 32 -> 64 bit multiplies), so every 32-bit word is spent on two elements.  The bit stream is implementation-defined.
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
@@ -235,8 +237,8 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 }
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, int64_t ldm, int64_t P, int C,
-                                                           uint32_t thresh24, uint64_t seed, uint64_t offset) {
-    const int G = (C + 3) >> 2;
+                                                           uint32_t thresh16, uint64_t seed, uint64_t offset) {
+    const int G = (C + 7) >> 3, C4 = ((C + 3) >> 2) << 2;
     const int64_t total = P * G;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(e % G);
@@ -249,11 +251,14 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
             k0 += 0x9E3779B9u;
             k1 += 0xBB67AE85u;
         }
-        const uint32_t rnd[4] = {c0, c1, c2, c3};
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) packed |= ((rnd[j] >> 8) >= thresh24 ? 1u : 0u) << (8 * j);   // keep with prob 1-p
-        *reinterpret_cast<uint32_t*>(mask + p * ldm + cg * 4) = packed;
+        // keep with probability 1 - p: element 2j from the low half of word j, element 2j + 1 from its high half
+        const uint32_t lo = ((c0 & 0xffffu) >= thresh16 ? 1u : 0u) | ((c0 >> 16) >= thresh16 ? 0x100u : 0u) |
+                            ((c1 & 0xffffu) >= thresh16 ? 0x10000u : 0u) | ((c1 >> 16) >= thresh16 ? 0x1000000u : 0u);
+        const uint32_t hi = ((c2 & 0xffffu) >= thresh16 ? 1u : 0u) | ((c2 >> 16) >= thresh16 ? 0x100u : 0u) |
+                            ((c3 & 0xffffu) >= thresh16 ? 0x10000u : 0u) | ((c3 >> 16) >= thresh16 ? 0x1000000u : 0u);
+        uint8_t* row = mask + p * ldm + cg * 8;
+        *reinterpret_cast<uint32_t*>(row) = lo;
+        if (cg * 8 + 4 < C4) *reinterpret_cast<uint32_t*>(row + 4) = hi;
     }
 }
 
@@ -261,10 +266,10 @@ extern "C" int uda_dropout_mask(uint8_t* mask, int64_t ldm, int64_t P, int C, fl
     UDA_REQUIRE(mask && (reinterpret_cast<uintptr_t>(mask) & 3u) == 0 && ldm % 4 == 0 && ldm >= ((C + 3) / 4) * 4 && P > 0 && C > 0,
                 "uda_dropout_mask: mask must be 4-byte aligned with ldm %% 4 == 0 and >= round4(C)");
     UDA_REQUIRE(p >= 0.f && p < 1.f, "uda_dropout_mask: p must be in [0, 1)");
-    const uint32_t thresh24 = (uint32_t)((double)p * 16777216.0);
-    int grid = uda_cdiv(P * ((C + 3) / 4), 256);
+    const uint32_t thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
+    int grid = uda_cdiv(P * ((C + 7) / 8), 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, ldm, P, C, thresh24, seed, offset);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, ldm, P, C, thresh16, seed, offset);
     UDA_LAUNCH_CHECK("dropout_mask");
     return 0;
 }

@@ -76,16 +76,60 @@ __global__ __launch_bounds__(256) void upconv_fwd_strip_kernel(const float* __re
     const int64_t total = (int64_t)N * H * W4 * G;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     int cg_mine = -1;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(e % G);
+    // consecutive workgroups share the low-resolution rows they read (every g row serves 4 output rows x 9 taps): the XCD remap keeps
+    // each XCD on a contiguous range of output rows, otherwise all eight L2s pull in all of g (302 MB at 32 images)
+    // index arithmetic in 32 bits (the host routes here only when every element count fits): the 64-bit divisions and the
+    // per-pixel 64-bit modulo of the addend row were a quarter of this kernel's instructions (1.65 k -> 1.4 k vector instructions per
+    // strip).  PMC: 59 % of the wave cycles are parked on memory at 3 waves per SIMD (134 VGPRs) - the kernel is latency-bound; batching
+    // the 18 loads of a row tap costs the third wave and is slower (886 vs 586 us on 32 images)
+    const int wg = uda_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned total32 = (unsigned)total, step32 = gridDim.x * blockDim.x, arows = (unsigned)add_rows;
+    const int ldg32 = (int)ldg, lda32 = (int)ld_add;
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)((int64_t)N * h * w * ldg * 4), 0x00020000);
+    for (unsigned e = (unsigned)wg * blockDim.x + threadIdx.x; e < total32; e += step32) {
+        const unsigned sp = e / (unsigned)G;
+        const int cg = (int)(e - sp * (unsigned)G);
         cg_mine = cg;
-        const int64_t sp = e / G;
-        const int ow0 = (int)(sp % W4) * 4, oh = (int)((sp / W4) % H), n = (int)(sp / ((int64_t)W4 * H));
-        const int64_t p0 = ((int64_t)n * H + oh) * W + ow0;
+        // strip order: four vertically adjacent strips are consecutive (with C = 256 the four waves of a workgroup)
+        const int k4 = (int)(sp & 3u);
+        const unsigned sq = sp >> 2, rq = sq / (unsigned)W4, H4 = (unsigned)(H >> 2);
+        const int ow0 = (int)(sq - rq * (unsigned)W4) * 4, n = (int)(rq / H4), oh = (int)(rq - (unsigned)n * H4) * 4 + k4;
+        const unsigned p0 = ((unsigned)n * (unsigned)H + (unsigned)oh) * (unsigned)W + (unsigned)ow0;
         float4 acc[4];
+        unsigned ar = addend ? p0 % arows : 0u;                 // addend row of the first pixel; the next ones wrap by comparison
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = addend ? uda_ld4(addend + ((p0 + j) % add_rows) * ld_add + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* gb = g + (int64_t)n * h * w * ldg + cg * 4;
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = addend ? uda_ld4(addend + (int64_t)ar * lda32 + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (++ar >= arows) ar = 0u;
+        }
+        const int gb_off = ((n * h * w) * ldg32 + cg * 4) * 4;       // byte offset of this image's / channel group's g (whole g < 2 GiB, host-checked)
+        // Column part, once per strip and horizontal tap (it does not depend on the row tap): the leftmost low-resolution column
+        // `a` the strip can read and, per output pixel j, the weight with which it reads column a + c (0 for a column it does
+        // not read and for a tap position outside the image) - the blend below is then NC multiply-adds per pixel, no selects.
+        int acol[3], coff[3][NC];                 // coff: byte offset of low-resolution column a + c (clamped) inside a g row
+        float cw[3][4][NC];
+        bool tw_on[3];
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) {
+            const int xb = ow0 + (tw - 1) * dil;                  // tap position of the strip's first pixel (may be outside)
+            tw_on[tw] = !(xb + 3 < 0 || xb >= W);
+            int a1;
+            float t0, t1;
+            bil_src(max(xb, 0), sw, w, acol[tw], a1, t0, t1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) coff[tw][c] = min(acol[tw] + c, w - 1) * (ldg32 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = xb + j;
+                int w0, w1;
+                float lw0, lw1;
+                bil_src(min(max(xx, 0), W - 1), sw, w, w0, w1, lw0, lw1);
+                const bool in = xx >= 0 && xx < W;
+                const int i0 = w0 - acol[tw], i1 = w1 - acol[tw];      // in [0, NC) by construction of NC
+#pragma unroll
+                for (int c = 0; c < NC; ++c) cw[tw][j][c] = in ? (i0 == c ? lw0 : 0.f) + (i1 == c ? lw1 : 0.f) : 0.f;
+            }
+        }
 #pragma unroll
         for (int th = 0; th < 3; ++th) {
             const int yy = oh + (th - 1) * dil;
@@ -93,45 +137,33 @@ __global__ __launch_bounds__(256) void upconv_fwd_strip_kernel(const float* __re
             int h0, h1;
             float lh0, lh1;
             bil_src(yy, sh, h, h0, h1, lh0, lh1);
+            const int ro0 = gb_off + h0 * w * (ldg32 * 4), ro1 = gb_off + h1 * w * (ldg32 * 4);
 #pragma unroll
             for (int tw = 0; tw < 3; ++tw) {
-                const int xb = ow0 + (tw - 1) * dil;              // tap position of the strip's first pixel (may be outside)
-                if (xb + 3 < 0 || xb >= W) continue;
-                int a, a1;
-                float t0, t1;
-                bil_src(max(xb, 0), sw, w, a, a1, t0, t1);        // a = leftmost low-resolution column the strip can read
-                const float* gt = gb + (th * 3 + tw) * C;
+                if (!tw_on[tw]) continue;
+                const int tapoff = (th * 3 + tw) * C * 4;         // scalar: the tap's column block of g
                 float4 v[NC];                                     // rows blended first: v[c] = lh0 * g[h0][a+c] + lh1 * g[h1][a+c]
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const int col = min(a + c, w - 1);
-                    const float4 r0 = uda_ld4(gt + ((int64_t)h0 * w + col) * ldg), r1 = uda_ld4(gt + ((int64_t)h1 * w + col) * ldg);
+                    const float4 r0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gres, ro0 + coff[tw][c], tapoff, 0));
+                    const float4 r1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gres, ro1 + coff[tw][c], tapoff, 0));
                     v[c] = make_float4(lh0 * r0.x + lh1 * r1.x, lh0 * r0.y + lh1 * r1.y, lh0 * r0.z + lh1 * r1.z, lh0 * r0.w + lh1 * r1.w);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int xx = xb + j;
-                    if (xx < 0 || xx >= W) continue;
-                    int w0, w1;
-                    float lw0, lw1;
-                    bil_src(xx, sw, w, w0, w1, lw0, lw1);
-                    const int i0 = w0 - a, i1 = w1 - a;           // in [0, NC) by construction of NC
-                    float4 c0 = v[0], c1 = v[0];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int c = 1; c < NC; ++c) {
-                        if (i0 == c) c0 = v[c];
-                        if (i1 == c) c1 = v[c];
+                    for (int c = 0; c < NC; ++c) {
+                        const float k = cw[tw][j][c];
+                        acc[j].x += k * v[c].x;
+                        acc[j].y += k * v[c].y;
+                        acc[j].z += k * v[c].z;
+                        acc[j].w += k * v[c].w;
                     }
-                    acc[j].x += lw0 * c0.x + lw1 * c1.x;
-                    acc[j].y += lw0 * c0.y + lw1 * c1.y;
-                    acc[j].z += lw0 * c0.z + lw1 * c1.z;
-                    acc[j].w += lw0 * c0.w + lw1 * c1.w;
-                }
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uda_st4(y + (p0 + j) * ldy + cg * 4, acc[j]);
+            uda_st4(y + (int64_t)(p0 + j) * ldy + cg * 4, acc[j]);
             s1[0] += acc[j].x; s1[1] += acc[j].y; s1[2] += acc[j].z; s1[3] += acc[j].w;
             s2[0] += acc[j].x * acc[j].x; s2[1] += acc[j].y * acc[j].y; s2[2] += acc[j].z * acc[j].z; s2[3] += acc[j].w * acc[j].w;
         }
@@ -154,15 +186,16 @@ __global__ __launch_bounds__(256) void upconv_fwd_strip_kernel(const float* __re
     (void)cg_mine;
 }
 
-static bool upconv_strip_ok(int w, int W, int C, int dil) {
+static bool upconv_strip_ok(int w, int W, int C, int dil, int H = 4) {
+    if (H % 4) return false;
     // the four tap positions of a strip span 3*sw low-resolution columns: floor(frac + 3*sw) + 1 <= NC - 1 with NC <= 4
     // (margins of 2 %: the column indices come from fp32 products scale * x, whose rounding must not push a strip over its last cached column)
-    return W % 4 == 0 && dil == 1 && C % 4 == 0 && 3.f * bil_scale(w, W) < 1.96f && 256 % (C / 4) == 0;
+    return W % 4 == 0 && dil == 1 && C % 4 == 0 && 3.f * bil_scale(w, W) < 1.96f && 256 % (C / 4) == 0;       // (+ H % 4 == 0, checked by the caller)
 }
 
 extern "C" int uda_upconv_fused_stats(int h, int w, int H, int W, int C, int dil) {
     (void)h; (void)H;
-    return upconv_strip_ok(w, W, C, dil) ? 1 : 0;
+    return upconv_strip_ok(w, W, C, dil, H) ? 1 : 0;
 }
 
 extern "C" int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, int C, int dil, const float* addend,
@@ -177,7 +210,9 @@ extern "C" int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, 
     hipStream_t st = (hipStream_t)stream;
     const float sh = bil_scale(h, H), sw = bil_scale(w, W);
     const int G = C / 4;
-    if (upconv_strip_ok(w, W, C, dil)) {
+    const int64_t lim32 = (int64_t)1 << 31;          // the strip kernel indexes in 32 bits
+    if (upconv_strip_ok(w, W, C, dil, H) && (int64_t)N * H * W < lim32 && (int64_t)N * H * (W / 4) * G < lim32 - 65536 * 256 &&
+        (int64_t)N * h * w * ldg * 4 < lim32 && (!addend || addend_rows * ld_add < lim32 * 4)) {
         const int64_t total = (int64_t)N * H * (W / 4) * G;
         int grid = uda_cdiv(total, 256);
         if (grid > 4096) grid = 4096;           // bounded: the statistics epilogue issues 2*C atomics per workgroup

@@ -8,7 +8,7 @@ set -o pipefail
 OUT=${1:-gpurun_out/prof}; shift
 WHAT=${@:-pf so rn pmc}
 EXTRA="${EXTRA:-} --no-other-mfma --no-host-input"
-PMC_MATCH=${PMC_MATCH:-igemm_conv_x3_kernel<3}
+PMC_MATCH=${PMC_MATCH:-igemm_conv_x3_kernel<3,x3_tail_reduce_kernel}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for w in $WHAT; do
@@ -20,7 +20,9 @@ for w in $WHAT; do
     pmc)
       rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/f.log 2>&1 || exit 1
       rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/w.log 2>&1 || exit 1
-      python3 profiles/pmc_traffic.py $(find $OUT/f -name '*counter_collection.csv') $(find $OUT/w -name '*counter_collection.csv') --match "$PMC_MATCH" > $OUT/traffic.json || exit 1
+      # conv calls of the run = bench.py's roofline.launches (1 timed step) x 2 (the warm-up step ran the same launches)
+      CALLS=$(grep '^{' $OUT/f.log | tail -1 | python3 -c "import sys, json; print(2 * json.loads(sys.stdin.read())['roofline']['launches'])")
+      python3 profiles/pmc_traffic.py $(find $OUT/f -name '*counter_collection.csv') $(find $OUT/w -name '*counter_collection.csv') --match "$PMC_MATCH" --calls $CALLS > $OUT/traffic.json || exit 1
       rm -rf $OUT/f $OUT/w
       continue ;;
   esac

@@ -477,11 +477,14 @@ static X3Tail x3_tail_plan(int64_t P, int Cout, int nchunks, int BM, int BN, boo
     t.full = (t.tiles / 256) * 256;
     t.tail = t.tiles - t.full;
     t.ksplit = 1;
-    if (allow && t.tail > 0 && t.tail <= 128) {
+    // only where it clearly pays: a long K (the fp32 partial tiles are extra traffic - one write and one read per split - and on the
+    // short-K layers the split bought 2-3 %) and at least three splits (measured: discriminator L3 / L4 forward 10 % / 16 %)
+    static const int mode = getenv("UDA_X3_TAIL_MODE") ? atoi(getenv("UDA_X3_TAIL_MODE")) : 1;      // experiment: 2 = every tail <= 128 tiles
+    if (allow && t.tail > 0 && (mode == 2 ? t.tail <= 128 : (t.tail <= 85 && nchunks >= 96))) {
         int s = (int)(256 / t.tail);
         if (s > 8) s = 8;
         if (s > nchunks / 8) s = nchunks / 8;       // at least 8 chunks per workgroup
-        if (s >= 2) t.ksplit = s;
+        if (s >= (mode == 2 ? 2 : 3)) t.ksplit = s;
     }
     return t;
 }

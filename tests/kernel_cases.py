@@ -447,6 +447,8 @@ CASES = [
     ("dw 576 s1 d1 border1", case_dw(2, 8, 8, 576, 1, 1, 1)),
     ("stem 2x3x32x32", case_stem(2, 32, 32)),
     ("stem 1x3x48x80", case_stem(1, 48, 80)),
+    ("stem 2x3x20x512 (row-staged kernels: Wo = 256)", case_stem(2, 20, 512)),
+    ("stem 1x3x7x1024 (row-staged kernels: two segments per row)", case_stem(1, 7, 1024)),
     # batch norm pieces
     ("bn C=32 P=3000", case_bn(3000, 32)),
     ("bn C=96 q1", case_bn(1500, 96, q1=True)),

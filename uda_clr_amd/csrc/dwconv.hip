@@ -580,6 +580,95 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
     }
 }
 
+// Row-staged variants for output rows that are a multiple of 256 pixels wide (the 512 x 512 training images: Wo = 256): a workgroup
+// owns 256 consecutive pixels of ONE output row, stages the three input rows x three channels it reads (513 columns each) in LDS
+// with coalesced loads, and computes from there.  (The generic kernels above fetch every tap with its own strided global load:
+// 27 loads per 16 bytes of output, 1.0-1.1 TB/s; these run at the rate of their 184 MB of traffic.)
+#define STEM_ROW_LD 516
+__device__ __forceinline__ void stem_stage_rows(const StemArgs& a, int n, int oh, int ow0, float* xin) {
+    const int64_t plane = (int64_t)a.H * a.W;
+    for (int e = threadIdx.x; e < 9 * 513; e += 256) {
+        const int r = e / 513, j = e - r * 513;                 // r = ci * 3 + kh
+        const int ci = r / 3, kh = r - ci * 3;
+        const int ih = oh * 2 - 1 + kh, iw = ow0 * 2 - 1 + j;
+        float v = 0.f;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.x[((int64_t)n * 3 + ci) * plane + (int64_t)ih * a.W + iw];
+        xin[r * STEM_ROW_LD + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_rows_kernel(StemArgs a) {
+    __shared__ float wsm[27 * 32];     // [tap][co]
+    __shared__ float xin[9 * STEM_ROW_LD];
+    __shared__ float red[32 * 2 * 32];
+    const int tid = threadIdx.x;
+    const int segs = a.Wo >> 8, seg = blockIdx.x % segs, row = blockIdx.x / segs, oh = row % a.Ho, n = row / a.Ho, ow0 = seg << 8;
+    for (int e = tid; e < 27 * 32; e += 256) wsm[e] = a.w[(e % 32) * 27 + e / 32];
+    stem_stage_rows(a, n, oh, ow0, xin);
+    __syncthreads();
+    const int cg = tid & 7, pl = tid >> 3, c0 = cg * 4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const int64_t pbase = ((int64_t)n * a.Ho + oh) * a.Wo + ow0;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int px = it * 32 + pl;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float v = xin[r * STEM_ROW_LD + 2 * px + kw];
+                const float4 ww = uda_ld4(&wsm[(r * 3 + kw) * 32 + c0]);
+                acc.x += ww.x * v; acc.y += ww.y * v; acc.z += ww.z * v; acc.w += ww.w * v;
+            }
+        uda_st4(a.y + (pbase + px) * a.ldy + c0, acc);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+    }
+    if (a.stats == nullptr) return;
+    uda_st4(&red[(pl * 2 + 0) * 32 + c0], s1);
+    uda_st4(&red[(pl * 2 + 1) * 32 + c0], s2);
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+        for (int p = 0; p < 32; ++p) t += red[p * 64 + tid];
+        atomicAdd(&a.stats[(int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 64 + tid], (double)t);
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_rows_kernel(StemArgs a) {
+    __shared__ float xin[9 * STEM_ROW_LD];
+    __shared__ float gs[256 * 33];     // 256 pixels x 32 channels
+    const int tid = threadIdx.x, co = tid & 31, tg = tid >> 5;
+    const int segs = a.Wo >> 8, seg = blockIdx.x % segs, row = blockIdx.x / segs, oh = row % a.Ho, n = row / a.Ho, ow0 = seg << 8;
+    const int64_t pbase = ((int64_t)n * a.Ho + oh) * a.Wo + ow0;
+    stem_stage_rows(a, n, oh, ow0, xin);
+    for (int e = tid; e < 256 * 8; e += 256) {
+        const int pp = e >> 3, c4 = (e & 7) * 4;
+        const float4 g = uda_ld4(a.dy + (pbase + pp) * a.lddy + c4);
+        gs[pp * 33 + c4] = g.x; gs[pp * 33 + c4 + 1] = g.y; gs[pp * 33 + c4 + 2] = g.z; gs[pp * 33 + c4 + 3] = g.w;
+    }
+    __syncthreads();
+    int xo[4];                          // LDS offset of tap tg + 8q at pixel 0 (a tap beyond 26 reads tap 0 and is not stored)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tap = tg + 8 * q < 27 ? tg + 8 * q : 0;
+        xo[q] = (tap / 3) * STEM_ROW_LD + tap % 3;               // tap = (ci * 3 + kh) * 3 + kw
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int pp = 0; pp < 256; ++pp) {
+        const float g = gs[pp * 33 + co];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += g * xin[xo[q] + 2 * pp];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tap = tg + 8 * q;
+        if (tap < 27) a.part[(int64_t)blockIdx.x * 864 + co * 27 + tap] = acc[q];
+    }
+}
+
 __global__ void cast_d2f_kernel(const double* __restrict__ in, int n, float* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) out[e] = (float)in[e];
@@ -601,7 +690,8 @@ extern "C" int uda_stem_fwd(const float* x, int N, int H, int W, const float* w,
     const int nwg = uda_cdiv(Pout, STEM_PIX_PER_WG);
     a.part = nullptr;
     a.stats = stats;
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
+    if (a.Wo % 256 == 0) hipLaunchKernelGGL(stem_fwd_rows_kernel, dim3(nwg), dim3(256), 0, st, a);       // nwg = N * Ho * (Wo / 256)
+    else hipLaunchKernelGGL(stem_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("stem_fwd");
     return 0;
 }
@@ -620,7 +710,8 @@ extern "C" int uda_stem_wgrad(const float* x, int N, int H, int W, const float* 
     double* sums = reinterpret_cast<double*>(workspace);
     a.part = workspace + 2 * 864;
     (void)hipMemsetAsync(sums, 0, 864 * sizeof(double), st);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+    if (a.Wo % 256 == 0 && uda_aligned16(dy) && lddy % 4 == 0) hipLaunchKernelGGL(stem_wgrad_rows_kernel, dim3(nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
     UDA_LAUNCH_CHECK("stem_wgrad");
     if (int e = uda_reduce_partials(a.part, nwg, 864, sums, st)) return e;
     hipLaunchKernelGGL(cast_d2f_kernel, dim3(uda_cdiv(864, 256)), dim3(256), 0, st, sums, 864, dw);

@@ -26,7 +26,7 @@ for w in $WHAT; do
       rm -rf $OUT/f $OUT/w
       continue ;;
   esac
-  MARK=stem_fwd_kernel; [ $w = rn ] && MARK=stem7_fwd_kernel
+  MARK=stem_fwd; [ $w = rn ] && MARK=stem7_fwd_kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w -o $w -- python3 bench.py $ARGS $EXTRA > $OUT/${w}_bench.log 2>&1 || exit 1
   grep '^{' $OUT/${w}_bench.log | tail -1 > $OUT/${w}_bench_line.json
   python3 profiles/summarize_trace.py $(find $OUT/$w -name '*kernel_trace.csv') --marker $MARK --per-step $PER --warmup 2 --steps 5 --by-grid "${BY_GRID:-_x3_kernel,igemm_conv_kernel,igemm_conv_ws_kernel,igemm_wgrad}" > $OUT/${w}_summary.txt || exit 1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel totals of the TIMED steps of a `rocprofv3 --kernel-trace` run of bench.py.
 
-    python profiles/summarize_trace.py <..._kernel_trace.csv> --marker stem_fwd_kernel --per-step 2 --warmup 2 --steps 5
+    python profiles/summarize_trace.py <..._kernel_trace.csv> --marker stem_fwd --per-step 2 --warmup 2 --steps 5
 
 The trace is cut at the first launch of `marker` that belongs to the first timed step (bench.py's warm-up
 steps hold MIOpen's one-off solver search for the stock-torch discriminators); `--per-step` = launches of the
@@ -14,7 +14,7 @@ import csv
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
-    ap.add_argument("--marker", default="stem_fwd_kernel")
+    ap.add_argument("--marker", default="stem_fwd")
     ap.add_argument("--per-step", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--steps", type=int, default=5)

@@ -543,12 +543,15 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, params: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
-                need_grad: bool, masks=None, repeat_prefix: bool = False, bn_training: Optional[bool] = None):
+                need_grad: bool, masks=None, repeat_prefix: bool = False, bn_training: Optional[bool] = None,
+                w_share: Optional[dict] = None):
         """``repeat_prefix`` (TransNorm only): run the deterministic part of the network (up to the ASPP output before its
         dropout and the decoder's low-level branch) as it comes out for the batch ``x.repeat(2, 1, 1, 1)`` - both TransNorm halves
         are x - without touching running statistics; returns (None, ctx) for ``mc_forward``."""
         K = self.K
         ctx = _Ctx()
+        if w_share is not None:          # kernel-side weight layouts (and their packed forms) shared by the passes of one step: the caller
+            ctx.w_cache = w_share        # promises that no parameter changes while it hands over the same dict (DeepLab.shared_weight_layouts)
         ctx.tn_repeat = bool(repeat_prefix and self.tn)
         ctx.params, ctx.x = params, x
         ctx.need_grad = bool(need_grad)

@@ -34,7 +34,7 @@ class _GeneratorFn(torch.autograd.Function):
         params = module._flat_state()
         masks, module._next_masks = module._next_masks, None
         bn_tr = module._bn_training()
-        outs, ectx = engine.forward(params, x, module.training, need_grad, masks, bn_training=bn_tr)
+        outs, ectx = engine.forward(params, x, module.training, need_grad, masks, bn_training=bn_tr, w_share=module._wshare)
         ctx.engine, ctx.ectx, ctx.keys, ctx.module = engine, ectx, keys, module
         if ectx is not None and module.training and bn_tr:      # (the MC fast path replays batch statistics: training-mode BN only)
             module._remember(x, ectx)
@@ -69,6 +69,7 @@ class DeepLab(Holder):
         self._generation = 0              # bumped whenever parameters / buffers / mode may have changed (note_params_changed)
         self._engine_override = None      # tests only: an engine bound to their torch kernel spec
         self._next_masks = None           # tests only: injected dropout keep-masks for one forward
+        self._wshare = None               # inside shared_weight_layouts(): {(key, kind): kernel-side layout} of the current parameters
         if freeze_bn:
             self.freeze_bn()
 
@@ -115,12 +116,31 @@ class DeepLab(Holder):
     def _forget(self, ectx):
         self._recent = [r for r in self._recent if r[4] is not ectx]
 
+    def shared_weight_layouts(self):
+        """Context manager: inside it every forward / backward of this module builds each kernel-side weight layout (relayouts,
+        bf16x3 packed rows) ONCE instead of once per pass.  The caller promises that no parameter changes inside the block
+        (torch's fused optimizer steps leave no trace a forward could check); ``note_params_changed`` / ``train`` /
+        ``load_state_dict`` drop the shared layouts.  ``Trainer_prototype_full`` holds it around the generator passes of a step
+        (target forward, source forward, MC passes and the backward up to ``optim_gen.step()``)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            keep, self._wshare = self._wshare, {}
+            try:
+                yield self
+            finally:
+                self._wshare = keep
+        return scope()
+
     def note_params_changed(self):
         """Invalidate the activations kept for ``mc_dropout_logits``: call after anything that changes parameters or buffers
         outside this module's sight (torch's fused optimizer steps do not bump tensor versions).  The bundled trainers call
         it after every optimizer step; ``train()`` / ``eval()`` / ``load_state_dict`` do it themselves."""
         self._generation += 1
         self._recent = []
+        if self._wshare is not None:
+            self._wshare = {}              # (a fresh dict: contexts of earlier passes keep theirs for their backward)
 
     def train(self, mode=True):
         self.note_params_changed()
@@ -144,7 +164,8 @@ class DeepLab(Holder):
             # repeated batch is still one forward of x (GeneratorEngine.forward(repeat_prefix=True)), shared by all passes
             with torch.no_grad():
                 engine = self._engine_for(x)
-                _, ectx = engine.forward(self._flat_state(), x.contiguous().float(), True, True, None, repeat_prefix=True)
+                _, ectx = engine.forward(self._flat_state(), x.contiguous().float(), True, True, None, repeat_prefix=True,
+                                         w_share=self._wshare)
                 return engine.mc_forward(ectx, reps, passes, masks=masks)
         for ptr, shape, version, generation, ectx in ([] if self.transnorm else self._recent):
             # the SAME tensor (address, shape, not written since) under the SAME parameters (no optimizer step, mode change or

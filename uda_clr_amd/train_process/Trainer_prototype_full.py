@@ -227,6 +227,16 @@ class Trainer(TrainerBase):
         imageS, target_map = self._to(sampleS['image']), self._to(sampleS['map'])
         target_boundary = self._to(sampleS['boundary'])
         imageT = self._to(sampleT['image'])
+        share = gen.shared_weight_layouts() if hasattr(gen, "shared_weight_layouts") else None
+        if share is not None:
+            share.__enter__()       # the generator's parameters do not change until optim_gen.step() below: one set of weight layouts
+        try:
+            return self._train_step_body(ops, gen, dis, dis2, gen_params, dis_params, imageS, imageT, target_map, target_boundary)
+        finally:
+            if share is not None:
+                share.__exit__(None, None, None)
+
+    def _train_step_body(self, ops, gen, dis, dis2, gen_params, dis_params, imageS, imageT, target_map, target_boundary):
         oT, boundaryT, _, _, xt_feature, oT_before, _ = gen(imageT)                          # :287
         oS, boundaryS, _, _, xs_feature, oS_before, _ = gen(imageS)                          # :288
         loss_seg = ops.seg_loss(oS, boundaryS, target_map, target_boundary)                  # :292-294

@@ -26,7 +26,7 @@ class PatchDiscriminatorEngine:
     def __init__(self, kernels):
         self.K = kernels
 
-    def forward(self, x, weights, need_grad, pre_op=0):
+    def forward(self, x, weights, need_grad, pre_op=0, w_share=None):
         """x: [N, C, H, W] (NCHW, as the reference feeds it).  ``pre_op`` 1 / 2: x holds generator LOGITS and the first layer
         reads sigmoid(x) / the uncertainty map -sigmoid(x) log(sigmoid(x) + 1e-7) (Trainer_prototype_full.py:452-454) - applied
         inside the space-to-depth pass, no full-resolution map is written.  Returns ([N, 1, Ho, Wo] logits, ctx)."""
@@ -37,9 +37,20 @@ class PatchDiscriminatorEngine:
         for li, w in enumerate(weights):
             O = w.shape[0]
             # z-space operands, built per forward (torch's fused optimizer steps do not bump a parameter's version,
-            # so a cross-forward cache could go stale unnoticed)
-            wf = K.relayout_s2d(w, False)
-            wd = K.relayout_s2d(w, True) if need_grad else None
+            # so a cross-forward cache could go stale unnoticed) - unless the caller hands over a dict and with it the promise
+            # that the weights do not change while it does (the passes of one training step: _PatchDiscriminator.shared_weight_layouts)
+            if w_share is None:
+                wf = K.relayout_s2d(w, False)
+                wd = K.relayout_s2d(w, True) if need_grad else None
+            else:
+                if (li, 0) not in w_share:
+                    w_share[(li, 0)] = K.relayout_s2d(w, False)
+                wf = w_share[(li, 0)]
+                wd = None
+                if need_grad:
+                    if (li, 1) not in w_share:
+                        w_share[(li, 1)] = K.relayout_s2d(w, True)
+                    wd = w_share[(li, 1)]
             Hz, Wz = _zgrid(vh), _zgrid(vw)
             z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
             if li == 0 and pre_op:

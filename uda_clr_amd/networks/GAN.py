@@ -16,7 +16,7 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, need, pre_op, *weights):
         engine = module._engine_for(x)
-        out, ectx = engine.forward(x.contiguous().float(), weights, need, pre_op)
+        out, ectx = engine.forward(x.contiguous().float(), weights, need, pre_op, w_share=module._wshare)
         ctx.engine, ctx.ectx, ctx.module, ctx.weights = engine, ectx, module, weights
         return out
 
@@ -47,11 +47,26 @@ class _PatchDiscriminator(nn.Module):
                 m.weight.data.normal_(0.0, 0.02)
         self._engine = None
         self._engine_override = None      # tests only: an engine bound to their torch kernel spec
+        self._wshare = None               # inside shared_weight_layouts(): z-space weight operands of the current parameters
         # which gradients a backward pass through this module produces: "auto" = whatever autograd needs;
         # "input" / "weights" let a training loop that back-propagates twice through ONE forward graph (generator
         # step, then discriminator step) skip the half it is not going to use (autograd cannot prune inside a
         # custom node).  The saved activations are released after an "auto" or "weights" pass.
         self.grad_mode = "auto"
+
+    def shared_weight_layouts(self):
+        """Context manager: the forwards inside it share one set of kernel-side weight operands (the caller promises that the
+        parameters do not change inside the block; see DeepLab.shared_weight_layouts)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            keep, self._wshare = self._wshare, {}
+            try:
+                yield self
+            finally:
+                self._wshare = keep
+        return scope()
 
     def _engine_for(self, x):
         if self._engine_override is not None:

@@ -227,14 +227,14 @@ class Trainer(TrainerBase):
         imageS, target_map = self._to(sampleS['image']), self._to(sampleS['map'])
         target_boundary = self._to(sampleS['boundary'])
         imageT = self._to(sampleT['image'])
-        share = gen.shared_weight_layouts() if hasattr(gen, "shared_weight_layouts") else None
-        if share is not None:
-            share.__enter__()       # the generator's parameters do not change until optim_gen.step() below: one set of weight layouts
-        try:
+        # the generator's parameters do not change until optim_gen.step(), the discriminators' until optim_dis.step() at the end of
+        # the step: one set of kernel-side weight layouts per module and step instead of one per pass
+        import contextlib
+        with contextlib.ExitStack() as stack:
+            for m in (gen, dis, dis2):
+                if hasattr(m, "shared_weight_layouts"):
+                    stack.enter_context(m.shared_weight_layouts())
             return self._train_step_body(ops, gen, dis, dis2, gen_params, dis_params, imageS, imageT, target_map, target_boundary)
-        finally:
-            if share is not None:
-                share.__exit__(None, None, None)
 
     def _train_step_body(self, ops, gen, dis, dis2, gen_params, dis_params, imageS, imageT, target_map, target_boundary):
         oT, boundaryT, _, _, xt_feature, oT_before, _ = gen(imageT)                          # :287

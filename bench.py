@@ -237,6 +237,83 @@ def cpu_baseline(workload, B, S, backbone="mobilenet"):
                          {k: round(v, 2) for k, v in probes.items()})}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher environment: become the launcher.  Starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>` as a CHILD
+    process (one rank per GPU over RCCL), relays rank 0's JSON line on stdout (everything else the ranks print goes to stderr) and
+    returns the child's exit code; a run without a JSON line is a failure.  The parent never touches the GPU: no torch.cuda call,
+    no HIP call - it only waits (a process that has initialised the GPU must not exec / fork GPU work on this pool)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank run exited with code %d\n" % (n, rc))
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the %d-rank run printed no result line\n" % n)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def stub_worker(args):
+    """Rehearsal of the launch + timing protocol WITHOUT a device (tests/test_bench_launcher.py): gloo ranks, a stub step (one small
+    all-reduce), the same barrier / max-over-ranks / one-JSON-line contract.  `data` says "stub"; it measures nothing."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus disagree" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo")
+    if os.environ.get("UDA_CLR_STUB_FAIL_RANK") == str(rank):       # a rank that dies: the launcher must hand the failure on
+        raise SystemExit(3)
+    x = torch.ones(1024)
+
+    def step():
+        y = x * 2.0
+        if world > 1:
+            dist.all_reduce(y)
+        return y
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert float(y[0]) == 2.0 * world
+    if rank == 0:
+        print(json.dumps({"metric": "stub step (launcher rehearsal, no device)", "value": round(world * args.steps / dt, 2), "unit": "steps/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "stub", "parallelism": "dp%d" % world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,7 +331,13 @@ def main():
                     help="matrix instructions of the wide conv tiles (default: UDA_CLR_MFMA or bf16x3)")
     ap.add_argument("--no-other-mfma", action="store_true", help="skip the short measurement of the other matrix mode")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive measurement (batches handed over from pinned host memory)")
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)   # launcher / timing-protocol rehearsal on CPU + gloo (tests)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent makes NO device call.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.stub_step:
+        return stub_worker(args)
     if args.mfma:
         os.environ["UDA_CLR_MFMA"] = args.mfma
     mode = os.environ.get("UDA_CLR_MFMA", "bf16x3").lower()
@@ -263,7 +346,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus disagree" % (args.gpus, world))
     if os.environ.get("UDA_CLR_SHARE_GPU"):      # rehearsal of the multi-process path on a one-GPU box (with the gloo backend)
         local = 0
     torch.cuda.set_device(local)

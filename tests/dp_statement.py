@@ -1,0 +1,96 @@
+"""Shared by the data-parallel tests of Trainer_prototype_full (gloo on CPU: tests/test_parallel_cpu.py; real devices:
+tests/test_parallel_gpu.py): the miniature of BASELINE.json configs[3] - two ranks x (B source + B target) - and the hand-made
+SINGLE-PROCESS statement of the same update on the concatenated batch, evaluated with the oracle on the host:
+  * both ranks end with IDENTICAL parameters (generator and both discriminators), although rank 1 started perturbed;
+  * the centroids on both ranks are the centroids of the CONCATENATED batch;
+  * the update equals one SGD step on  mean_r(seg_r + adv_r) + pro_weight * intra(global centroids).
+Test infrastructure (imports oracle/)."""
+import torch
+import torch.nn.functional as F
+
+PF = dict(S=128, B=2, lr=0.05, lr_d=0.01, pro_weight=0.1, loaderS_seed=80, loaderT_seed=90, drop_seed=500)
+
+
+def proto_setup(seed_dis=1338):
+    """The oracle generator (seed 1337 parameters of the product's DeepLab) and the oracle discriminators."""
+    from oracle import deeplab_ref
+    from oracle.gan_ref import BoundaryDiscriminator, UncertaintyDiscriminator
+    from uda_clr_amd.networks.deeplabv3 import DeepLab
+    torch.manual_seed(1337)
+    m = deeplab_ref.OracleDeepLab(DeepLab(num_classes=2, backbone="mobilenet", output_stride=16).state_dict())
+    torch.manual_seed(seed_dis)
+    d1, d2 = BoundaryDiscriminator(), UncertaintyDiscriminator()
+    return m, d1, d2
+
+
+def rank_record(tr, m, d1, d2, vals):
+    """What a rank saves after its train_step (CPU tensors)."""
+    c = lambda t: t.detach().cpu().clone()
+    return {"gen": {k: c(v) for k, v in m.named_parameters()}, "dis": {k: c(v) for k, v in d1.named_parameters()},
+            "dis2": {k: c(v) for k, v in d2.named_parameters()}, "src": [c(t) for t in tr.src_centroids],
+            "tgt": [c(t) for t in tr.tgt_centroids], "vals": vals}
+
+
+def check_ranks_agree(r0, r1):
+    for grp in ("gen", "dis", "dis2"):
+        for k in r0[grp]:
+            assert torch.equal(r0[grp][k], r1[grp][k]), "ranks diverged on %s %s" % (grp, k)
+    for a, b in zip(r0["src"] + r0["tgt"], r1["src"] + r1["tgt"]):
+        assert torch.equal(a, b), "the ranks hold different centroids"
+    assert r0["vals"][4:] == r1["vals"][4:], "intra / inter are global quantities"
+
+
+def check_global_statement(r0, rtol_cent=1e-4, rtol_loss=1e-4, rtol_gen=2e-4, atol_gen=2e-6, rtol_dis=2e-4, atol_dis=1e-7):
+    """r0: rank 0's record.  Rebuilds the step on the host as ONE process over both ranks' batches and compares."""
+    from make_golden_inputs import synth_loader
+    from oracle import proto_ref, step_ref
+    c = PF
+    m, d1, d2 = proto_setup()
+    m.train(); d1.train(); d2.train()
+    init = {g: {k: v.detach().clone() for k, v in mod.named_parameters()} for g, mod in (("gen", m), ("dis", d1), ("dis2", d2))}
+    loaderS, loaderT = synth_loader(2, c["B"], c["S"], c["loaderS_seed"]), synth_loader(2, c["B"], c["S"], c["loaderT_seed"])
+    per = []
+    for r in range(2):
+        torch.manual_seed(c["drop_seed"] + r)
+        sS, sT = loaderS[r], loaderT[r]
+        oT, bT, _, _, xt, oT_before, _ = m(sT["image"])
+        oS, bS, _, _, xs, _, _ = m(sS["image"])
+        rep = sT["image"].repeat(2, 1, 1, 1)
+        with torch.no_grad():
+            preds = torch.cat([m(rep)[0] for _ in range(4)], 0)
+        per.append(dict(oT=oT, bT=bT, xt=xt, oTb=oT_before, oS=oS, bS=bS, xs=xs, preds=preds, sS=sS))
+    # global source centroids: labels nearest-resized, features of both ranks concatenated
+    lab = torch.cat([F.interpolate(p["sS"]["map"].clone(), size=p["xs"].shape[2:], mode="nearest") for p in per])
+    src = proto_ref.gen_prototype(lab, torch.cat([p["xs"] for p in per]))
+    # global target centroids: the retrify weights are per pixel, so the concatenated batch gives the concatenated weights
+    T = 8
+    preds_cat = torch.cat([torch.cat([p["preds"][i * c["B"]:(i + 1) * c["B"]] for p in per]) for i in range(T)])
+    tgt = proto_ref.gen_prototype_retrify(torch.cat([p["oTb"] for p in per]), torch.cat([p["xt"] for p in per]), preds_cat, T,
+                                          2 * c["B"])[:4]
+    for got, want in zip(r0["src"] + r0["tgt"], src + tgt):
+        assert torch.allclose(got.reshape(-1), want.detach().reshape(-1), rtol=rtol_cent, atol=rtol_cent * 1e-2), \
+            "centroids are not those of the global batch"
+    intra, inter = proto_ref.alignment_losses(src, tgt)
+    assert abs(r0["vals"][4] - intra.item()) < rtol_loss * abs(intra.item()) and abs(r0["vals"][5] - inter.item()) < rtol_loss * abs(inter.item())
+    total = c["pro_weight"] * intra
+    for p in per:
+        adv = 0.01 * (step_ref._adv(d2(step_ref._uncertainty(p["oT"])), 1) + step_ref._adv(d1(torch.sigmoid(p["bT"])), 1))
+        total = total + 0.5 * (step_ref.seg_loss(p["oS"], p["bS"], p["sS"]["map"], p["sS"]["boundary"]) + adv)
+    gp = [q for q in m.parameters()]
+    grads = torch.autograd.grad(total, gp, allow_unused=True)
+    worst = {}
+    for (k, v0), g in zip(init["gen"].items(), grads):
+        want = v0 if g is None else v0 - c["lr"] * g
+        assert torch.allclose(r0["gen"][k], want, rtol=rtol_gen, atol=atol_gen), (k, (r0["gen"][k] - want).abs().max().item())
+        worst[k] = (r0["gen"][k] - want).abs().max().item()
+    # discriminators: mean over ranks of (D_same_r + D_diff_r) on detached generator outputs
+    dl = 0.0
+    for p in per:
+        oS, bS, oT, bT = (p[k].detach() for k in ("oS", "bS", "oT", "bT"))
+        dl = dl + 0.5 * (step_ref._adv(d2(step_ref._uncertainty(oS)), 1) + step_ref._adv(d1(torch.sigmoid(bS)), 1) +
+                         step_ref._adv(d2(step_ref._uncertainty(oT)), 0) + step_ref._adv(d1(torch.sigmoid(bT)), 0))
+    for grp, mod in (("dis", d1), ("dis2", d2)):
+        ps = list(mod.parameters())
+        for (k, v0), g in zip(init[grp].items(), torch.autograd.grad(dl, ps, retain_graph=True)):
+            assert torch.allclose(r0[grp][k], v0 - c["lr_d"] * g, rtol=rtol_dis, atol=atol_dis), (grp, k)
+    return worst

@@ -124,13 +124,16 @@ class _AlignFn(torch.autograd.Function):
         ctx.save_for_backward(new_src, new_tgt)
         ctx.w = (1.0 if prev_src is None else decay, 1.0 if prev_tgt is None else decay)
         ctx.mark_non_differentiable(new_src, new_tgt)
+        ctx.set_materialize_grads(False)        # an unused output arrives as None, not as a zero tensor: no device read needed below
         return losses[0], losses[1], new_src, new_tgt
 
     @staticmethod
     def backward(ctx, g_intra, g_inter, _a, _b):
         new_src, new_tgt = ctx.saved_tensors
-        if g_inter is not None and bool((g_inter != 0).any()):
+        if g_inter is not None:
             raise NotImplementedError("inter_loss is logged only (Trainer_prototype_full.py:443-449, :465); no gradient is built for it")
+        if g_intra is None:
+            return None, None, None, None, None
         d_src, d_tgt = kernels().proto_align_bwd(new_src, new_tgt, g_intra.reshape(1).contiguous().float(), ctx.w[0], ctx.w[1])
         return d_src, d_tgt, None, None, None
 

@@ -26,7 +26,8 @@ def proto_setup(seed_dis=1338):
 def rank_record(tr, m, d1, d2, vals):
     """What a rank saves after its train_step (CPU tensors)."""
     c = lambda t: t.detach().cpu().clone()
-    return {"gen": {k: c(v) for k, v in m.named_parameters()}, "dis": {k: c(v) for k, v in d1.named_parameters()},
+    # (the oracle module names its parameters with "__" for ".": one spelling for both kinds of generator)
+    return {"gen": {k.replace("__", "."): c(v) for k, v in m.named_parameters()}, "dis": {k: c(v) for k, v in d1.named_parameters()},
             "dis2": {k: c(v) for k, v in d2.named_parameters()}, "src": [c(t) for t in tr.src_centroids],
             "tgt": [c(t) for t in tr.tgt_centroids], "vals": vals}
 
@@ -47,7 +48,7 @@ def check_global_statement(r0, rtol_cent=1e-4, rtol_loss=1e-4, rtol_gen=2e-4, at
     c = PF
     m, d1, d2 = proto_setup()
     m.train(); d1.train(); d2.train()
-    init = {g: {k: v.detach().clone() for k, v in mod.named_parameters()} for g, mod in (("gen", m), ("dis", d1), ("dis2", d2))}
+    init = {g: {k.replace("__", "."): v.detach().clone() for k, v in mod.named_parameters()} for g, mod in (("gen", m), ("dis", d1), ("dis2", d2))}
     loaderS, loaderT = synth_loader(2, c["B"], c["S"], c["loaderS_seed"]), synth_loader(2, c["B"], c["S"], c["loaderT_seed"])
     per = []
     for r in range(2):

@@ -84,12 +84,8 @@ def _run(backend, share):
         mp.spawn(_worker, args=(2, port, out, backend, share), nprocs=2, join=True)
         r0, r1 = torch.load(os.path.join(out, "pf0.pt")), torch.load(os.path.join(out, "pf1.pt"))
     dp_statement.check_ranks_agree(r0, r1)
-    # the host statement is the fp32 oracle; the HIP path sits at its usual distance from it (forward 1e-4, gradients a few 1e-3
-    # of their scale on this 128^2, B = 2 case: one SGD step of lr 0.05 on them)
-    worst = dp_statement.check_global_statement(r0, rtol_cent=2e-3, rtol_loss=5e-3, rtol_gen=5e-2, atol_gen=2e-4, rtol_dis=5e-3,
-                                                atol_dis=2e-6)
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
-    print("largest generator update differences to the host statement:", top)
+    gmean, top = dp_statement.check_against_fp64_statement(r0)
+    print("generator update vs the fp64 statement: noise ratio to the fp32 statement (geometric mean) %.2f; largest distances" % gmean, top)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the one-GPU variant below covers the rest")

@@ -78,13 +78,18 @@ def test_trainer_baseline_hip_matches_reference_rows(golden_dir, tmp_path):
 def test_trainer_baseline_hip_matches_reference_rows_256(golden_dir, tmp_path):
     """BASELINE.json configs[0] shape (8 x 256^2, one epoch of 4 Adam steps + validation), rows written by the reference's own
     Trainer_baseline: every BatchNorm sees >= 2048 samples, so two fp32 evaluation orders stay on one trajectory and the
-    whole epoch is held to 1 % (first step, a pure forward quantity: 1e-3; measured 0.3-0.5 % after 3 Adam steps).  The
-    validation loss (eval mode on running statistics that saw 4 updates: a BCE of 4.2) is the touchiest number of the fixture:
-    the REFERENCE arithmetic itself moves it by 1.6 % between 1 and 8 host threads (4.2696 vs 4.2041, torch CPU fp32).  The HIP path in
-    f32 mode lands 0.03 % from the fixture (bound 2 %); in bf16x3 mode - another, equally accurate summation order (gradient noise
-    against the fp64 oracle 0.77 in both modes, tests/tools/grad_noise_seeds.py) - the four Adam steps end 0.7 % away on the last training
-    row and the saturated eval-mode BCE follows by 9-11 % (3.73-3.83 over the tile choices, measured at the end of round 2; 2.5 % with
-    the first version of the kernel): bound 15 % there, as for the 64^2 fixture.  Dice to 0.01 in both modes."""
+    training rows are held to 1 % (first step, a pure forward quantity: 1e-3; measured 0.3-0.5 % after 3 Adam steps).
+
+    The validation loss (eval mode on running statistics that saw 4 updates: a saturated BCE of ~4) gets ONE bound for both
+    matrix modes, 15 %, and it is the reference arithmetic's own scatter, not a concession to a mode.  tests/tools/trajectory_anchor.py
+    replays this fixture in float64 and in four fp32 arithmetics (profiles/r03_trajectory_anchor.txt, measured on the MI355X
+    box): float64 3.866; the oracle in fp32 on 1 host thread 3.783 (-2.2 %), on 16 threads 4.217 (+9.1 %); the fixture itself
+    (the reference in the build container) 4.204 (+8.7 %); HIP f32 mode 4.180 (+8.1 %), HIP bf16x3 mode 3.859 (-0.2 %).  Every fp32
+    arithmetic makes the same per-step error when restarted from the float64 state (6e-2 of the update on Adam's first,
+    sign-like step, 3-8e-3 afterwards, equal in all four to two digits), evaluates the float64 end state to 1e-7, and the
+    parameters drift from the float64 trajectory at the same rate (0.28-0.29 of the update after 4 steps): the spread of the
+    validation loss is the fixture's conditioning, and the fixture's own value is one draw of it (two fp32 evaluations of the
+    REFERENCE differ by 11 % of it).  Dice to 0.01 in both modes."""
     z = json.load(open(os.path.join(golden_dir, "trainer_baseline_256.json")))
     m = MaskFeeder(model_cases.seeded_model().to(DEV))
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
@@ -108,9 +113,7 @@ def test_trainer_baseline_hip_matches_reference_rows_256(golden_dir, tmp_path):
     txt = ",".join(val[0])
     got = [float(v) for v in txt[txt.index("(") + 1: txt.index(")")].split(",")]
     print("val hip", got, "reference", z["val"][0])
-    from uda_clr_amd.kernels import HipKernels
-    bound = 0.02 if HipKernels().mfma == HipKernels.MFMA_F32 else 0.15
-    assert abs(got[0] - z["val"][0][0]) < bound * abs(z["val"][0][0])
+    assert abs(got[0] - z["val"][0][0]) < 0.15 * abs(z["val"][0][0])          # one bound for both matrix modes (docstring)
     assert abs(got[1] - z["val"][0][1]) < 0.01 and abs(got[2] - z["val"][0][2]) < 0.01
 
 

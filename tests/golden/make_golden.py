@@ -20,6 +20,7 @@ inputs and stores inputs' seeds + expected outputs as small data files:
   trainer_*.json         loss rows written by the reference's own Trainer loops
   input_pipeline.json, input_pipeline_small.npz   outputs of the reference's dataloaders/custom_transforms.py on seeded samples
   forward_frozen_64.npz  DeepLab(freeze_bn=True) in training mode (eval-mode BatchNorm, live dropout): outputs, loss, gradient norms
+  forward_frozen_tn_64.npz  the same for DeepLab(sync_bn=False, freeze_bn=True): frozen TransNorm layers, B = 4
 
 While generating, every fixture is also compared with the oracle restatement (oracle/), so a
 successful run pins the oracle against the reference on full tensors, not only on the samples
@@ -215,29 +216,50 @@ def make_forward(m, B, S, tag, do_eval=True):
     np.savez_compressed(os.path.join(HERE, "forward_%s.npz" % tag), **out)
 
 
-def make_frozen(B=2, S=64):
-    """DeepLab(freeze_bn=True) (deeplabv3.py:43-50; train_use_fix_initial.py:92-96 turns any --freeze-bn value into True): the
+def make_frozen(B=2, S=64, transnorm=False):
+    """transnorm=True: DeepLab(sync_bn=False, freeze_bn=True) - freeze_bn() evals the TransNorm layers too (deeplabv3.py:47-50), so
+    the TARGET running statistics normalise and the gain 1 + alpha comes from both domains' running statistics
+    (batchnorm.py:497-520) -> forward_frozen_tn_64.npz.
+    DeepLab(freeze_bn=True) (deeplabv3.py:43-50; train_use_fix_initial.py:92-96 turns any --freeze-bn value into True): the
     BatchNorm modules sit in eval mode (running statistics normalise, nothing is updated) while the model itself trains -
     dropout active, gamma / beta and all weights receive gradients.  Running statistics and affine parameters are perturbed
     (seeded) so the frozen statistics differ from the batch's."""
     from networks.deeplabv3 import DeepLab
     from oracle import deeplab_ref, step_ref
     torch.manual_seed(1337)
-    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=True, freeze_bn=True, method="prototype_full")
+    from networks.sync_batchnorm.batchnorm import BatchNorm2d as RefTransNorm
+    m = DeepLab(num_classes=2, backbone="mobilenet", output_stride=16, sync_bn=not transnorm, freeze_bn=True, method="prototype_full")
     g = torch.Generator().manual_seed(5)
     for k, v in m.state_dict().items():
-        if k.endswith("running_mean"):
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf.startswith("running_mean"):           # incl. TransNorm's *_source / *_target buffers
             v.copy_(0.1 * torch.randn(v.shape, generator=g))
-        elif k.endswith("running_var"):
+        elif leaf.startswith("running_var"):
             v.copy_(0.5 + torch.rand(v.shape, generator=g))
     for mod in m.modules():
-        if isinstance(mod, torch.nn.BatchNorm2d):
+        if isinstance(mod, (torch.nn.BatchNorm2d, RefTransNorm)):
             assert not mod.training
             mod.weight.data.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
             mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
     assert m.training
+    if transnorm:
+        # TransNorm scales every layer by 1 + alpha (2 on average): on statistics that do not describe the activations the network
+        # is un-normalised and any two fp32 evaluation orders drift apart ~2.3x per block.  So the frozen statistics are CALIBRATED:
+        # one training-mode forward with momentum 1 on a 6-image batch whose halves differ (running := batch statistics per domain)
+        bns = [mod for mod in m.modules() if isinstance(mod, RefTransNorm)]
+        for mod in bns:
+            mod.train()
+            mod.momentum = 1.0
+        xc = torch.randn(6, 3, S, S, generator=torch.Generator().manual_seed(1))
+        xc[3:] = 0.6 * xc[3:] - 0.3
+        with torch.no_grad():
+            m(xc)
+        for mod in bns:
+            mod.momentum = 0.1
+        m.freeze_bn()
+        assert m.training and not any(mod.training for mod in bns)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
-    out = {"B": B, "S": S, "input_seed": 0, "dropout_seed": 7, "target_seed": 11, "perturb_seed": 5}
+    out = {"B": B, "S": S, "input_seed": 0, "dropout_seed": 7, "target_seed": 11, "perturb_seed": 5, "calibration_seed": 1}
     torch.manual_seed(0)
     x = torch.randn(B, 3, S, S)
     tmap, tbd = synth_targets(B, S, S, 11)
@@ -271,7 +293,7 @@ def make_frozen(B=2, S=64):
             assert torch.equal(rs[k], sd0[k]), "frozen statistics moved: " + k
     for k, v in rec.items():
         out["mask." + k + ".sum"] = np.int64(v.sum().item())
-    np.savez_compressed(os.path.join(HERE, "forward_frozen_%d.npz" % S), **out)
+    np.savez_compressed(os.path.join(HERE, "forward_frozen_%s%d.npz" % ("tn_" if transnorm else "", S)), **out)
 
 
 def make_proto():
@@ -585,10 +607,14 @@ def make_input_pipeline():
 if __name__ == "__main__":
     import tempfile
     install_reference()
-    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tb256", "tp", "rn", "tn", "input", "frozen", "rntn"]
+    which = sys.argv[1:] or ["manifest", "fwd64", "fwd512", "proto", "metrics", "tb", "tb256", "tp", "rn", "tn", "input", "frozen", "rntn", "frozentn"]
     if "frozen" in which:
         make_frozen()
         if which == ["frozen"]:
+            raise SystemExit(0)
+    if "frozentn" in which:
+        make_frozen(B=4, transnorm=True)
+        if which == ["frozentn"]:
             raise SystemExit(0)
     if "input" in which:
         make_input_pipeline()

@@ -143,6 +143,11 @@ def train_parity(dev, B=2, S=64, extra_heads=True, backbone="mobilenet", output_
         m._engine_override = engine
     bn_tr = None
     if frozen_bn:                    # DeepLab.freeze_bn() while training (deeplabv3.py:43-50): eval-mode BatchNorm, live dropout
+        if transnorm:                # frozen TransNorm statistics must describe the activations (every layer is scaled by 1 + alpha)
+            SHc, SWc = (S, S) if isinstance(S, int) else S
+            xc = torch.randn(6, 3, SHc, SWc, generator=torch.Generator().manual_seed(1))
+            xc[3:] = 0.6 * xc[3:] - 0.3
+            calibrate_running_stats(m, xc)
         m.freeze_bn()
         bn_tr = False
     gen = torch.Generator().manual_seed(seed)

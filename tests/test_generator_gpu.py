@@ -348,6 +348,51 @@ def test_frozen_batchnorm_training_matches_oracle_and_reference_fixture():
     assert rel_gn.max() < 3e-2 and np.median(rel_gn) < 5e-3, (rel_gn.max(), np.median(rel_gn))
 
 
+def test_frozen_transnorm_training_matches_oracle_and_reference_fixture():
+    """DeepLab(sync_bn=False).freeze_bn() while training on the HIP kernels (deeplabv3.py:47-50 evals the TransNorm layers too): the
+    target running statistics normalise, the gain 1 + alpha of both domains' running statistics is a constant of the pass; against
+    the fp64 oracle and against the fixture the reference's own DeepLab(sync_bn=False, freeze_bn=True) wrote on calibrated
+    statistics (forward_frozen_tn_64.npz)."""
+    import os
+    import numpy as np
+    from make_golden_inputs import synth_targets
+    from oracle import deeplab_ref, step_ref
+    fwd, grads, stats, _ = model_cases.train_parity(DEV, B=4, transnorm=True, frozen_bn=True, seed=11)
+    assert max(fwd.values()) < 1e-3, fwd
+    assert stats == 0.0
+    errs = sorted(v[0] for v in grads.values())
+    assert errs[-1] < 8e-2 and errs[len(errs) // 2] < 3e-2, (errs[-1], errs[len(errs) // 2])      # bounds: the plain-BN frozen test above
+    z = np.load(os.path.join(model_cases.GOLDEN, "forward_frozen_tn_64.npz"))
+    B, S = int(z["B"]), int(z["S"])
+    m = model_cases.seeded_model(perturb=True, transnorm=True).train()
+    xc = torch.randn(6, 3, S, S, generator=torch.Generator().manual_seed(int(z["calibration_seed"])))
+    xc[3:] = 0.6 * xc[3:] - 0.3
+    model_cases.calibrate_running_stats(m, xc)
+    m.freeze_bn()
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    rec = {}
+    torch.manual_seed(int(z["dropout_seed"]))
+    with torch.no_grad():
+        deeplab_ref.deeplab_forward(deeplab_ref.canonical_state({k: v.clone() for k, v in m.state_dict().items()}), x, training=True,
+                                    record=rec, bn_training=False)
+    m.to(DEV)
+    m.set_dropout_masks(rec)
+    out = m(x.to(DEV))
+    loss = step_ref.seg_loss(out[0], out[1], tmap.to(DEV), tbd.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-3 * float(z["train.loss"])
+    for n, t in zip(model_cases.NAMES, out):
+        a = t.detach().double().abs().sum().item()
+        assert abs(a - float(z["train.%s.abs" % n])) < 1e-3 * float(z["train.%s.abs" % n]), n
+    live = m._flat_state()
+    gn = np.array([live[str(k)].grad.double().norm().item() for k in z["train.grad_keys"]])
+    rel_gn = np.abs(gn - z["train.grad_norm"]) / np.maximum(z["train.grad_norm"], 1e-12)
+    print("frozen TransNorm gradient norms vs the reference fixture: worst %.2e median %.2e" % (rel_gn.max(), np.median(rel_gn)))
+    assert rel_gn.max() < 3e-2 and np.median(rel_gn) < 5e-3, (rel_gn.max(), np.median(rel_gn))
+
+
 def test_resnet_transnorm_on_the_hip_kernels():
     """DeepLab(backbone='resnet', sync_bn=False) (deeplabv3.py:17-23): per-domain-half launches of the ResNet-101 sequence on
     the HIP kernels against the fp64 oracle (halves of 2 + 2 images), and against the fixture the reference's own model wrote

@@ -257,3 +257,56 @@ def test_resnet_transnorm_engine_matches_oracle():
     bad, gmean = model_cases.grads_ok(grads)
     assert not bad, list(bad.items())[:10]
     assert gmean < 1.5, gmean
+
+
+def test_frozen_transnorm_training_matches_oracle_and_reference_fixture(golden_dir):
+    """DeepLab(sync_bn=False).freeze_bn() while training (deeplabv3.py:47-50 evals both BN kinds; reachable through
+    train_use_fix_initial.py:92-100,180-185 with --use_TN and any --freeze-bn): the TARGET running statistics normalise, the gain
+    1 + alpha comes from both domains' running statistics (batchnorm.py:497-520) and is a constant of the pass; dropout is live,
+    gamma / beta / weights receive gradients.  (1) the oracle's frozen TransNorm mode reproduces the fixture the reference's own
+    DeepLab(sync_bn=False, freeze_bn=True) wrote (forward_frozen_tn_64.npz: loss 1e-6, every gradient norm 1e-4); (2) the engine
+    (torch statement of the kernels) against the fp64 oracle with the frozen-BN criterion; no running buffer moves."""
+    z = np.load(os.path.join(golden_dir, "forward_frozen_tn_64.npz"))
+    B, S = int(z["B"]), int(z["S"])
+    m = _tn_model()                   # perturbed exactly like the fixture's model (generator seed 5, same draw order) ...
+    xc = torch.randn(6, 3, S, S, generator=torch.Generator().manual_seed(int(z["calibration_seed"])))
+    xc[3:] = 0.6 * xc[3:] - 0.3
+    _calibrate_running_stats(m, xc)   # ... and calibrated like it (frozen statistics that describe the activations)
+    torch.manual_seed(int(z["input_seed"]))
+    x = torch.randn(B, 3, S, S)
+    tmap, tbd = synth_targets(B, S, S, int(z["target_seed"]))
+    osd = deeplab_ref.canonical_state({k: v.clone() for k, v in m.state_dict().items()}, requires_grad=True)
+    torch.manual_seed(int(z["dropout_seed"]))
+    ref = deeplab_ref.deeplab_forward(osd, x, training=True, bn_training=False)
+    loss_ref = step_ref.seg_loss(ref[0], ref[1], tmap, tbd)
+    loss_ref.backward()
+    assert abs(loss_ref.item() - float(z["train.loss"])) < 1e-6
+    keys = [str(k) for k in z["train.grad_keys"]]
+    np.testing.assert_allclose([osd[k].grad.double().norm().item() for k in keys], z["train.grad_norm"], rtol=1e-4)
+    # (2)
+    fwd, grads, stats, _ = model_cases.train_parity(torch.device("cpu"), B=4, transnorm=True, frozen_bn=True,
+                                                    engine=GeneratorEngine(SpecKernels(), transnorm=True), seed=11)
+    assert max(fwd.values()) < 2e-4, fwd
+    assert stats == 0.0               # frozen statistics: bit-identical to where they started
+    model_cases.frozen_grads_ok(grads)
+
+
+def test_mc_passes_with_frozen_transnorm_run_as_plain_forwards():
+    """The MC fast path replays batch statistics, which a frozen model does not have: mc_dropout_logits must fall through to
+    plain training-mode forwards (frozen statistics, live dropout) and equal them."""
+    m = _tn_model().train()
+    xc = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    xc[3:] = 0.6 * xc[3:] - 0.3
+    _calibrate_running_stats(m, xc)
+    m.freeze_bn()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    masks = [deeplab_ref.draw_masks(4, 64, 64, g)]
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    fast = m.mc_dropout_logits(x, passes=1, reps=2, masks=masks)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    osd = deeplab_ref.canonical_state(sd0)
+    with torch.no_grad():
+        want = deeplab_ref.deeplab_forward(osd, x.repeat(2, 1, 1, 1), training=True, masks=masks[0], bn_training=False)[0]
+    assert _rel(fast, want) < 2e-4

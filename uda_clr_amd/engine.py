@@ -250,7 +250,21 @@ class GeneratorEngine:
         rmt, rvt = p[prefix + ".running_mean_target"], p[prefix + ".running_var_target"]
         if not training:
             K.tn_eval_coeffs(g, b, rms, rvs, rmt, rvt, BN_EPS, scale, shift)
-            return None
+            if not ctx.need_grad:
+                return None
+            # frozen TransNorm inside a training pass (DeepLab.freeze_bn evals both BN kinds, deeplabv3.py:47-50; eval branch
+            # batchnorm.py:497-520): z = ((x - mu_t) / sigma_t * gamma + beta) * gain with gain = 1 + alpha from the RUNNING
+            # statistics of both domains, a constant of the pass.  scale / shift above already carry gain, so dx = scale * g is
+            # right as it stands; dgamma / dbeta are gain * the plain sums (as for the per-half training records).
+            rs, rt = rms / torch.sqrt(rvs + BN_EPS), rmt / torch.sqrt(rvt + BN_EPS)
+            prob = 1.0 / (1.0 + (rs - rt).abs())
+            gain = 1.0 + prob.numel() * prob / prob.sum()
+            istd = torch.rsqrt(rvt + BN_EPS)
+            if mean is not None:
+                mean.copy_(rmt)
+                invstd.copy_(istd)
+                return BNRec(prefix, mean, invstd, float("inf"), q1, gain, frozen=True)
+            return BNRec(prefix, rmt, istd, float("inf"), q1, gain, frozen=True)
         if ctx.tn_repeat:
             # the batch is x repeated twice, so both halves have x's statistics: distance 0, alpha = 1, every channel scaled
             # by exactly 2.  Plain coefficients over x, doubled; the running buffers of both domains get their updates from
@@ -525,7 +539,10 @@ class GeneratorEngine:
                 if e.bn.frozen:
                     # quirk Q1 with a frozen depthwise BN behind: the gradient summed over ALL padded positions of the block input
                     # is colsum(dy_dw) * sum of the depthwise taps = scale_dw * dbeta_dw * sum_t w (engine docstring)
-                    q1_total = (d.scale * G[pre + kdb + ".bias"] * ctx.params[pre + kd + ".weight"].sum((1, 2, 3))).contiguous()
+                    dbeta = G[pre + kdb + ".bias"]
+                    if d.bn.gain is not None:          # frozen TransNorm: dbeta carries the gain, colsum(dy_dw) = scale * sum(g) does not need it twice
+                        dbeta = dbeta / d.bn.gain
+                    q1_total = (d.scale * dbeta * ctx.params[pre + kd + ".weight"].sum((1, 2, 3))).contiguous()
                 dye = self._bn_backward(ctx, G, e, dUe, q1_total=q1_total)
                 self._wgrad(ctx, G, pre + ".conv.0.weight", zin, dye, 1, 1)
                 d_zin = self._buf(x, zin.P, zin.C)
@@ -559,8 +576,6 @@ class GeneratorEngine:
         # DeepLab.freeze_bn() turns off while the model keeps training (deeplabv3.py:43-50)
         drop_tr = training
         training = training if bn_training is None else bool(bn_training)
-        if self.tn and training != drop_tr:
-            raise NotImplementedError("frozen TransNorm layers inside a training pass are not built")
         S = ctx.S
         N, _, Hin, Win = x.shape
         if Hin % 16 or Win % 16:
@@ -781,6 +796,8 @@ class GeneratorEngine:
         K.bnbwd_apply(dU, y, cg[0], cg[1], out, addend)
         if y.split:
             dg, db = (cg[2] * y.bn.gain).sum(0), (cg[3] * y.bn.gain).sum(0)
+        elif y.bn.gain is not None and y.bn.frozen:      # frozen TransNorm: one coefficient set, the constant gain on the affine gradients
+            dg, db = cg[2] * y.bn.gain, cg[3] * y.bn.gain
         else:
             dg, db = cg[2], cg[3]
         if keys is None:
@@ -900,14 +917,17 @@ class GeneratorEngine:
             gaing = A["grec"].gain
         else:
             cnt4, cntg, gain4, gaing = A["brecs"][0].count, A["grec"].count, None, None      # P16 and N, or inf when frozen
+            if A["brecs"][0].gain is not None:      # frozen TransNorm: the constant gains of the four branches / the pooling branch
+                gain4, gaing = torch.cat([r.gain for r in A["brecs"]]), A["grec"].gain
         c4 = Act(cat[:, :1024], N, H16, W16, coef[0][..., w4], coef[1][..., w4], ACT_RELU, None, 1.0,
-                 BNRec("aspp", coef[2][..., w4], coef[3][..., w4], cnt4, False, gain4), split=catA.split)
+                 BNRec("aspp", coef[2][..., w4], coef[3][..., w4], cnt4, False, gain4, frozen=A["brecs"][0].frozen), split=catA.split)
         keys = [("aspp.aspp%d.bn" % j, slice(256 * (j - 1), 256 * j)) for j in (1, 2, 3, 4)]
         dyc = self._bn_backward(ctx, G, c4, dUc[:, :1024], keys=keys)
         dUg = self._empty(x, N, 256)
         K.gap_fwd(dUc[:, 1024:1280], N, dUg, 1.0)
         yga = Act(A["yg"], N, 1, 1, coef[0][..., wg], coef[1][..., wg], ACT_RELU, None, 1.0,
-                  BNRec("aspp.global_avg_pool.2", coef[2][..., wg], coef[3][..., wg], cntg, False, gaing), split=catA.split)
+                  BNRec("aspp.global_avg_pool.2", coef[2][..., wg], coef[3][..., wg], cntg, False, gaing, frozen=A["grec"].frozen),
+                  split=catA.split)
         dyg = self._bn_backward(ctx, G, yga, dUg)
         self._wgrad(ctx, G, "aspp.global_avg_pool.1.weight", A["gpa"], dyg, 1, 1)
         d_gp = self._empty(x, N, self.c_high)

@@ -158,7 +158,7 @@ class DeepLab(Holder):
         every optimizer step), the deterministic pre-dropout activations of that forward are reused and only the dropout-dependent tail is recomputed
         (``GeneratorEngine.mc_forward``); otherwise the passes run as plain forwards."""
         assert self.training, "stochastic passes need training mode (dropout + batch statistics)"
-        if self.transnorm and reps == 2:
+        if self.transnorm and reps == 2 and self._bn_training():
             # TransNorm splits the REPEATED batch into its two copies of x (identical statistics: alpha = 1, gain 2), not into the
             # halves of x the grad-mode forward saw: nothing of that forward can be reused, but the deterministic part of the
             # repeated batch is still one forward of x (GeneratorEngine.forward(repeat_prefix=True)), shared by all passes

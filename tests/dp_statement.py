@@ -145,5 +145,8 @@ def check_against_fp64_statement(r0):
     for grp in ("dis", "dis2"):
         for k, w64 in s64[grp].items():
             u64 = w64 - s64["init"][grp][k]
-            assert model_cases.l2rel(r0[grp][k].double() - s64["init"][grp][k], u64) < 2e-3, (grp, k)
+            e_hip = model_cases.l2rel(r0[grp][k].double() - s64["init"][grp][k], u64)
+            e_32 = model_cases.l2rel((s32[grp][k] - s32["init"][grp][k]).double(), u64)
+            # (the discriminators see the generator's outputs: the fp32 statement itself is 3-7e-3 from fp64 on these updates)
+            assert model_cases.grad_ok(e_hip, e_32), (grp, k, e_hip, e_32)
     return gmean, sorted(errs.items(), key=lambda kv: -kv[1][0])[:3]

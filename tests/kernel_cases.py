@@ -821,6 +821,17 @@ CASES += [
     ("conv3x3 160->60 dil2 mask stats (x3 256 x 64 tile)", case_conv(1, 45, 41, 160, 60, 3, 2, mask=True)),
     ("conv2x2 o1 256->56 addend (x3 256 x 64 tile)", case_conv(2, 30, 30, 256, 56, 2, 1, lazy=False, addend=True, origin=1)),
 ]
+# narrow 1x1 convs: 64-pixel tiles when 128-pixel tiles would leave half of the CUs without a workgroup (the 32x32-map layers at
+# B = 16: P = 16384), and the 128-pixel tiles of the same routes on more pixels (round 3)
+CASES += [
+    ("conv1x1 384->64 P=16384 relu6 stats (64-pixel tiles)", case_conv(16, 32, 32, 384, 64, 1, 1)),
+    ("conv1x1 576->96 P=16384 addend no stats (64-pixel tiles, 128 columns)", case_conv(16, 32, 32, 576, 96, 1, 1, addend=True, stats=False)),
+    ("conv1x1 192->30 P=5655 ragged mask bias (64-pixel tiles)", case_conv(3, 65, 29, 192, 30, 1, 1, mask=True, bias=True)),
+    ("dgrad1x1 64<-384 P=16384 accumulate (64-pixel tiles)", case_dgrad(16, 32, 32, 64, 384, 1, 1, accumulate=True)),
+    ("conv1x1 384->64 P=32000 ragged stats (128-pixel tiles)", case_conv(2, 125, 128, 384, 64, 1, 1)),
+    ("conv1x1 96->24 P=40000 raw addend (128-pixel tiles)", case_conv(1, 200, 200, 96, 24, 1, 1, lazy=False, addend=True)),
+    ("conv1x1 64->96 P=28900 relu6 mask (128-pixel tiles)", case_conv(1, 170, 170, 64, 96, 1, 1, mask=True)),
+]
 
 
 # ---------------------------------------------------------------- input pipeline tail: bit-exact against scipy

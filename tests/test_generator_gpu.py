@@ -480,3 +480,55 @@ def test_per_gpu_batch_32_at_512_properties():
     for k, v in m.state_dict().items():
         if "running" in k:
             assert model_cases.rel(s_fast[k], v) < 1e-4, k
+
+
+# ---- BASELINE.json configs[4]: the ResNet-101 variant at its full per-GPU shape, 8 images of 512 x 512
+def test_resnet101_per_gpu_batch_8_at_512_properties():
+    """Size-independent properties at the full configs[4] shape (the CPU oracle runs the 128^2 / 256^2 fixtures, not this):
+      * eval forward: batch independence - images 2..3 of the batch of 8 alone give the same outputs;
+      * training forward + backward: permuting the images (and their injected dropout masks) permutes the outputs and leaves the
+        parameter gradients and the running statistics unchanged (batch statistics and weight gradients are sums over the batch);
+      * gradients are finite and every parameter receives one."""
+    B, S = 8, 512
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(B, 3, S, S, generator=g, device=DEV)
+    keep = lambda shp, p: (torch.rand(shp, generator=g, device=DEV) >= p).to(torch.uint8)
+    sites = {"aspp.dropout": ((256, S // 16, S // 16), 0.5), "decoder.last_conv_boundary.3": ((256, S // 4, S // 4), 0.5),
+             "decoder.last_conv_boundary.7": ((256, S // 4, S // 4), 0.1), "decoder.last_conv.2": ((305, S // 4, S // 4), 0.1)}
+    masks = {k: keep((B,) + shp, p) for k, (shp, p) in sites.items()}
+    m = model_cases.seeded_model(perturb=True, backbone="resnet").to(DEV)
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        part = m(x[2:4].contiguous())
+    for n, a, b in zip(model_cases.NAMES, full, part):
+        assert model_cases.rel(a[2:4], b) < 1e-5, n
+    del full, part
+    tmap = (torch.rand(B, 2, S, S, generator=g, device=DEV) > 0.5).float()
+    tbd = torch.rand(B, 1, S, S, generator=g, device=DEV)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    runs = []
+    from uda_clr_amd import ops
+    for p in (None, perm):
+        m.load_state_dict(sd0)
+        m.train()
+        for q in m.parameters():
+            q.grad = None
+        sel = (lambda t: t) if p is None else (lambda t: t[p].contiguous())
+        m.set_dropout_masks({k: sel(v) for k, v in masks.items()})
+        out = m(sel(x))
+        ops.seg_loss(out[0], out[1], sel(tmap), sel(tbd)).backward()
+        runs.append((out[0].detach(), {k: q.grad.clone() for k, q in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+        del out
+    (o0, g0, r0), (o1, g1, r1) = runs
+    assert all(bool(torch.isfinite(v).all()) for v in g0.values()) and len(g0) == len(list(m.parameters()))
+    assert model_cases.rel(o1, o0[perm]) < 2e-4
+    for k in r0:
+        assert model_cases.rel(r1[k], r0[k]) < 1e-5, k
+    # two summation orders of the same batch sums through 101 layers of training-mode BN (the BN-affine gradients are
+    # near-cancelling sums): the median tensor agrees to 1e-4, the worst to a few 1e-3
+    errs = sorted((model_cases.l2rel(g1[k], g0[k]), k) for k in g0)
+    print("resnet-101 B=8 512^2: permutation test, median %.2e worst %s" % (errs[len(errs) // 2][0], errs[-1]))
+    assert errs[len(errs) // 2][0] < 5e-4 and errs[-1][0] < 2e-2, (errs[len(errs) // 2], errs[-1])

@@ -189,3 +189,45 @@ def test_flat_adam_matches_torch_adam_and_keeps_the_checkpoint_layout():
     for x, y in zip(pc, pb):
         assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
     assert float(oc.state_dict()["state"][0]["step"]) == 5.0
+
+
+def test_flat_adam_parameter_without_gradient_and_rebound_data():
+    """(1) A parameter that never receives a gradient: torch skips it and keeps a step count per parameter; FlatAdam hands over
+    to torch's own step at the first such step and must match a plain torch.optim.Adam from then on (values and per-parameter
+    step counts).  (2) A p.data rebound after the first step (what a .to() or a manual assignment does) is noticed at the next
+    step and the flat buffers are rebuilt around the current values instead of updating an orphaned buffer."""
+    from uda_clr_amd.optim import FlatAdam, take_over
+    g = torch.Generator().manual_seed(1)
+    shapes = [(8, 3), (5,), (4, 4)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)]
+    # (1)
+    pa, pb = mk(), mk()
+    oa, ob = take_over(torch.optim.Adam(pa, lr=1e-2, betas=(0.9, 0.99))), torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99))
+    assert isinstance(oa, FlatAdam)
+    for it in range(4):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if i == 1 and it >= 2:                       # the middle parameter loses its gradient from the third step on
+                x.grad = y.grad = None
+                continue
+            gr = torch.randn(x.shape, generator=g).to(DEV)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert [float(sa["state"][k]["step"]) for k in sorted(sa["state"])] == [float(sb["state"][k]["step"]) for k in sorted(sb["state"])] == [4.0, 2.0, 4.0]
+    # (2)
+    pa, pb = mk(), mk()
+    oa, ob = take_over(torch.optim.Adam(pa, lr=1e-2, betas=(0.9, 0.99))), torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99))
+    for it in range(3):
+        if it == 1:
+            pa[2].data = pa[2].data.clone()              # no longer a view of the flat buffer
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).to(DEV)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7), (x - y).abs().max()
+    assert float(oa.state_dict()["state"][2]["step"]) == 3.0

@@ -43,6 +43,15 @@ __device__ __forceinline__ float uda_act_gate(float a, int act) {
     return 1.f;
 }
 
+// Host side: slot of the current device for per-device one-time setup (hipFuncSetAttribute is per device; one process may drive
+// several, although the trainers use one process per GPU).
+#define UDA_MAX_DEVICES 16
+static inline int uda_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d % UDA_MAX_DEVICES;
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch).  Give every XCD one contiguous chunk of
 // the logical tile order so neighbouring tiles (shared halo rows / shared weight panels) hit the
 // same 4 MiB L2.  Bijective for any nwg (cdna_hip_programming.md, 8-phase template notes).

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void conv_heads_kernel(ConvKArgs a) {
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    static_assert(BM == 128, "stats partial layout assumes 128-pixel tiles");
+    static_assert(BM == 128 || BM == 64, "tiles of 128 or 64 pixels");
     k.nMt = uda_cdiv(P, BM);
     k.nNt = uda_cdiv(k.Cout, BN);
     hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
@@ -502,7 +502,12 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
         UDA_LAUNCH_CHECK("conv_heads");
         return 0;
     }
+    // few pixels (the 32x32-map layers at B = 16: 128 tiles of 128 pixels for 256 CUs): 64-pixel tiles, twice the workgroups
+    static const int low_env = getenv("UDA_CONV_LOW") ? atoi(getenv("UDA_CONV_LOW")) : 1;
+    const bool low = low_env && P > 64 && uda_cdiv(P, 128) * uda_cdiv(a->Cout, a->Cout <= 64 ? 64 : 128) <= 192;
     if (uda_conv_uses_x3(a)) e = launch_conv_x3(k, P, a->x3_src, a->x3_w, st, a->workspace, a->workspace_bytes);
+    else if (low && a->Cout <= 64) e = launch_conv<1, 1, 2, 2>(k, P, st);
+    else if (low && a->Cout <= 128 && (k.Ktot <= 192 || a->Cout <= 96 || (a->ksize >= 2 && k.Kc < IG_BK))) e = launch_conv<1, 2, 2, 2>(k, P, st);
     else if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);
     else if (a->Cout <= 64) e = launch_conv<1, 2, 4, 1>(k, P, st);
     else if (a->Cout <= 96) e = launch_conv<1, 3, 4, 1>(k, P, st);

@@ -349,7 +349,8 @@ static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int MW = BM == 64 ? 4 : ((BM == 256 || TN % 2 == 0) ? UDA_WS_MATH_WAVES_EVEN : 4);
     constexpr size_t lds = 2 * (BM + BN) * IG_LD * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static bool configured = false;
+    static bool configured_dev[UDA_MAX_DEVICES] = {};       // hipFuncSetAttribute is per device
+    bool& configured = configured_dev[uda_device_slot()];
     auto fn = igemm_conv_ws_kernel<KS, XF, TN, MW, BM>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -358,7 +359,11 @@ static int launch_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
     }
     k.nMt = uda_cdiv(P, BM);
     k.nNt = uda_cdiv(k.Cout, BN);
+    #ifdef UDA_DIAG          // diagnostic builds only (make DIAG=1): the ablation modes change the results
     static const int dbg = getenv("UDA_WS_DEBUG") ? atoi(getenv("UDA_WS_DEBUG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     k.debug = dbg;
     hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3((MW + 4) * 64), lds, st, k);
     UDA_LAUNCH_CHECK("igemm_conv_ws");
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(BIG ? 768 : 512) void igemm_wgrad_ws_kernel(WgradKA
 template <int KS, int XF, bool BIG>
 static int launch_wg(WgradKArgs& k, int S, hipStream_t st) {
     constexpr size_t lds = 2 * WG_BKP * (BIG ? 512 : 256) * sizeof(float);
-    static bool configured = false;
+    static bool configured_dev[UDA_MAX_DEVICES] = {};       // hipFuncSetAttribute is per device
+    bool& configured = configured_dev[uda_device_slot()];
     auto fn = igemm_wgrad_ws_kernel<KS, XF, BIG>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

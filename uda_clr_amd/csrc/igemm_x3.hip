@@ -498,7 +498,8 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, 
     constexpr int BN = 64 * TN;
     constexpr size_t lds = 2 * (BM + BN) * X3_ROW * sizeof(__bf16);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static bool configured = false;
+    static bool configured_dev[UDA_MAX_DEVICES] = {};       // hipFuncSetAttribute is per device
+    bool& configured = configured_dev[uda_device_slot()];
     auto fn = igemm_conv_x3_kernel<KS, TN, BM>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -507,7 +508,11 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, 
     }
     k.nMt = uda_cdiv(P, BM);
     k.nNt = uda_cdiv(k.Cout, BN);
+    #ifdef UDA_DIAG          // diagnostic builds only (make DIAG=1): bit0 skips the MFMAs - results are WRONG with it
     static const int dbg = getenv("UDA_X3_DEBUG") ? atoi(getenv("UDA_X3_DEBUG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     k.debug = dbg;
     X3Tail t = x3_tail_plan(P, k.Cout, k.nchunks, BM, BN, k.stats == nullptr && ws != nullptr);
     if (x3_tail_bytes(t, BM, BN) > ws_bytes) t.ksplit = 1;
@@ -519,7 +524,8 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, 
     }
     if (t.ksplit > 1) {
         k.tile_off = (int)t.full; k.ksplit = t.ksplit; k.partial = reinterpret_cast<float*>(ws);
-        static bool configured_tail = false;
+        static bool configured_tail_dev[UDA_MAX_DEVICES] = {};
+        bool& configured_tail = configured_tail_dev[uda_device_slot()];
         auto fnt = igemm_conv_x3_kernel<KS, TN, BM, true>;
         if (!configured_tail) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fnt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -870,7 +876,8 @@ int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_sr
     x.cps = uda_cdiv(x.nchunks, S);
     S = uda_cdiv(x.nchunks, x.cps);
     S_out = S;
-    static bool configured = false;
+    static bool configured_dev[UDA_MAX_DEVICES] = {};       // hipFuncSetAttribute is per device
+    bool& configured = configured_dev[uda_device_slot()];
     auto ldsz = [](int bm, int bn) { return (size_t)2 * 3 * 16 * ((bm * 2 + 64) + (bn * 2 + 64)); };
     if (!configured) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_x3_kernel<256, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz(256, 256));

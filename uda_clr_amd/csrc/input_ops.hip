@@ -219,7 +219,8 @@ extern "C" int uda_field_smooth(const double* noise, int B, int H, int W, const 
     const size_t lds = ((size_t)(FS_TILE + 2 * radius) * FS_LD + radius + 1) * sizeof(double);
     UDA_REQUIRE(lds <= 160 * 1024, "uda_field_smooth: radius %d needs %zu B of LDS (limit 160 KiB: sigma up to ~61, sides up to ~768)", radius, lds);
     hipStream_t st = (hipStream_t)stream;
-    static bool configured = false;
+    static bool configured_dev[UDA_MAX_DEVICES] = {};       // hipFuncSetAttribute is per device
+    bool& configured = configured_dev[uda_device_slot()];
     if (!configured) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(field_smooth_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(field_smooth_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -11,8 +11,12 @@ torch optimizer's own, per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), b
   * performs the update of a whole group with one launch of ``uda_adam_step`` on the flat buffers (the gradients are gathered
     into a fourth flat buffer with one multi-tensor copy).
 
-A step in which some parameter of the group has no gradient, or a configuration the kernel does not cover (weight decay,
-amsgrad, maximize, non-fp32 / non-device parameters), runs the torch optimizer's own ``step`` on the same (view) tensors.
+A configuration the kernel does not cover (weight decay, amsgrad, maximize, non-fp32 / non-device parameters) is left to the
+torch optimizer.  The first step in which some parameter has no gradient hands the optimizer back to torch's own ``step`` for
+good (on the same view tensors): torch skips such a parameter and keeps a step count PER parameter, which one shared count
+cannot represent.  Every step checks (host-side pointer compares) that each ``p.data`` still is its view of the flat buffer
+and re-flattens otherwise (a ``.to()`` or a manual ``p.data = ...`` after the first step would otherwise leave the optimizer
+updating an orphaned buffer).
 """
 from __future__ import annotations
 
@@ -49,6 +53,7 @@ class FlatAdam:
         self._K = kernels
         self._groups = None
         self._step = 0
+        self._torch_steps = False      # True once a step met a parameter without gradient: torch's own rule from then on
 
     # ---------------------------------------------------------------- torch.optim.Optimizer surface the trainers / scripts use
     @property
@@ -69,6 +74,8 @@ class FlatAdam:
     def load_state_dict(self, sd):
         self.inner.load_state_dict(sd)
         self._groups = None            # re-flatten from the loaded per-parameter tensors on the next step
+        self._step = 0                 # (taken from the loaded state by _build; an empty state starts at 0 again)
+        self._torch_steps = False
 
     # ---------------------------------------------------------------- flat layout
     def _kernels(self):
@@ -114,8 +121,17 @@ class FlatAdam:
             self._step = steps[0]
         self._sync_steps()
 
+    def _aliased(self):
+        """every parameter still is its view of the flat buffer (host-side compares only)"""
+        for G in self._groups:
+            base = G.flat_p.data_ptr()
+            for p, off in zip(G.params, G.offsets):
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or p.device != G.flat_p.device:
+                    return False
+        return True
+
     def _sync_steps(self):
-        if self._groups is None:
+        if self._groups is None or self._torch_steps:      # (torch's own per-parameter counts are the truth in that mode)
             return
         for G in self._groups:
             for p in G.params:
@@ -127,13 +143,19 @@ class FlatAdam:
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("FlatAdam.step takes no closure")
+        if self._torch_steps:
+            return self.inner.step()
         if self._groups is None:
             self._build()
+        elif not self._aliased():
+            self._sync_steps()          # someone rebound a p.data: adopt the current values and moments into fresh flat buffers
+            self._build()
         if any(p.grad is None for G in self._groups for p in G.params):
-            self._sync_steps()          # some parameter has no gradient: torch's own rule (skip it) on the same view tensors
-            self.inner.step()
-            self._step += 1
-            return
+            # some parameter has no gradient: torch's rule skips it and does not advance ITS step count, which the one shared count
+            # of the flat update cannot follow - torch's own step (on the same view tensors) from here on
+            self._sync_steps()
+            self._torch_steps = True
+            return self.inner.step()
         self._step += 1
         K = self._kernels()
         for G, g in zip(self._groups, self.inner.param_groups):

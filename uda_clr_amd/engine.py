@@ -161,9 +161,6 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------ small helpers
     def _check_arena(self, ctx):
-        import os
-        if os.environ.get("UDA_CLR_OVERLAP_TS") == "1":     # EXPERIMENT (timing only)
-            return
         if ctx.arena is not None:
             bad = ~torch.isfinite(ctx.arena.buf.sum())
             self.nonfinite = bad if self.nonfinite is None else (self.nonfinite | bad)

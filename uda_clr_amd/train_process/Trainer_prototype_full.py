@@ -237,25 +237,8 @@ class Trainer(TrainerBase):
             return self._train_step_body(ops, gen, dis, dis2, gen_params, dis_params, imageS, imageT, target_map, target_boundary)
 
     def _train_step_body(self, ops, gen, dis, dis2, gen_params, dis_params, imageS, imageT, target_map, target_boundary):
-        import os
-        if os.environ.get("UDA_CLR_OVERLAP_TS") == "1" and imageT.is_cuda and hasattr(gen, "_wshare"):     # EXPERIMENT (timing only)
-            main = torch.cuda.current_stream()
-            if not hasattr(self, "_side"):
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
-            keep, gen._wshare = gen._wshare, {}
-            with torch.cuda.stream(self._side):
-                outT = gen(imageT)
-            gen._wshare = keep
-            outS = gen(imageS)
-            main.wait_stream(self._side)
-            for t in outT:
-                t.record_stream(main)
-            oT, boundaryT, _, _, xt_feature, oT_before, _ = outT
-            oS, boundaryS, _, _, xs_feature, oS_before, _ = outS
-        else:
-            oT, boundaryT, _, _, xt_feature, oT_before, _ = gen(imageT)                          # :287
-            oS, boundaryS, _, _, xs_feature, oS_before, _ = gen(imageS)                          # :288
+        oT, boundaryT, _, _, xt_feature, oT_before, _ = gen(imageT)                          # :287
+        oS, boundaryS, _, _, xs_feature, oS_before, _ = gen(imageS)                          # :288
         loss_seg = ops.seg_loss(oS, boundaryS, target_map, target_boundary)                  # :292-294
         scalars = [loss_seg.detach()]
         intra_loss = None

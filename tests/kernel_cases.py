@@ -832,6 +832,14 @@ CASES += [
     ("conv1x1 96->24 P=40000 raw addend (128-pixel tiles)", case_conv(1, 200, 200, 96, 24, 1, 1, lazy=False, addend=True)),
     ("conv1x1 64->96 P=28900 relu6 mask (128-pixel tiles)", case_conv(1, 170, 170, 64, 96, 1, 1, mask=True)),
 ]
+# bf16x3 on long-K 1x1 convs towards >= 256 outputs (ResNet-101's bottleneck convs on the 32x32 maps, round 3)
+CASES += [
+    ("conv1x1 1024->256 P=8192 raw stats (x3 long-K 1x1)", case_conv(8, 32, 32, 1024, 256, 1, 1, lazy=False)),
+    ("conv1x1 2048->512 P=2312 relu ragged (x3 long-K 1x1)", case_conv(2, 34, 34, 2048, 512, 1, 1)),
+    ("dgrad1x1 1024<-256 P=8192 accumulate (x3 wide 1x1)", case_dgrad(8, 32, 32, 1024, 256, 1, 1, accumulate=True)),
+    ("wgrad1x1 1024->256 P=8192 raw (x3 long-K 1x1)", case_wgrad(8, 32, 32, 1024, 256, 1, 1, lazy=False)),
+    ("wgrad1x1 2048->512 P=4624 relu (x3 long-K 1x1)", case_wgrad(4, 34, 34, 2048, 512, 1, 1)),
+]
 
 
 # ---------------------------------------------------------------- input pipeline tail: bit-exact against scipy

@@ -550,7 +550,11 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, 
 // the 256 x 64 tile; 1x1 convs only when very wide (256 -> 2304 tap GEMM of the re-associated decoder conv: 1.6-1.8x; 1280 -> 256
 // at 16384 pixels: 1.0x, stays on the fp32 pipe).
 bool conv_x3_eligible(const ConvKArgs& k) {
-    if (k.ksize == 1) return k.Kc >= 128 && k.Cout >= 1024;     // (measured with Cout >= 128: the backbone's 1x1 convs gain nothing, the packing pass eats it)
+    // 1x1: very wide outputs (the 256 -> 2304 tap GEMM), or a long K towards >= 256 outputs (ResNet-101's bottleneck convs 1024 -> 256 and
+    // 2048 -> 512 on the 32x32 maps: their operands are block inputs / gradients that the weight gradient packs anyway).
+    // (measured with Cout >= 128 on MobileNetV2's 1x1 convs: they gain nothing, the packing pass eats it)
+    static const int long_k = getenv("UDA_X3_LONGK_1X1") ? atoi(getenv("UDA_X3_LONGK_1X1")) : 1;
+    if (k.ksize == 1) return k.Kc >= 128 && (k.Cout >= 1024 || (long_k && k.Kc >= 1024 && k.Cout >= 256));
     return k.Kc >= IG_BK && k.Cout * k.ksize * k.ksize >= 432;
 }
 
@@ -846,7 +850,8 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
 // Eligibility of the weight gradient: 16-wide channel blocks must not straddle taps (Kc % 16 == 0), enough work to pay for the
 // packing of dy (the source's packed form usually exists already from the forward conv).
 bool wgrad_x3_eligible(int Cin, int Cout, int ksize, int64_t P) {
-    if (ksize == 1) return Cin % 16 == 0 && Cin >= 128 && Cout >= 1024 && P >= 4096;
+    static const int long_k = getenv("UDA_X3_LONGK_1X1") ? atoi(getenv("UDA_X3_LONGK_1X1")) : 1;
+    if (ksize == 1) return Cin % 16 == 0 && P >= 4096 && ((Cin >= 128 && Cout >= 1024) || (long_k && Cin >= 1024 && Cout >= 256));
     return Cin % 16 == 0 && Cin >= 32 && Cout >= 96 && P >= 4096;
 }
 

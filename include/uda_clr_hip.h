@@ -179,6 +179,19 @@ int uda_s2d_fwd(const float* src, int64_t ld_src, int nchw_in, int N, int Hs, in
                 int valid_w, float slope, float* z, int64_t ld_z, int Hz, int Wz, void* stream);
 int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, int Hz, int Wz, float slope, int N, int Hs,
                 int Ws, int C, int valid_h, int valid_w, float* dst, int64_t ld_dst, int nchw_out, void* stream);
+/* uda_s2d_bwd (rows out) with the LeakyReLU gate read from the sign of the forward's SOURCE rows [N, Hs, Ws, C] (the previous
+ * layer's raw output: z = lrelu(source), same signs) - for when the fp32 z image was never written, see below. */
+int uda_s2d_bwd_gate(const float* dz, int64_t ld_z, int Hz, int Wz, const float* gate_rows, int64_t ld_gate, float slope,
+                     int N, int Hs, int Ws, int C, int valid_h, int valid_w, float* dst, int64_t ld_dst, void* stream);
+/* bf16x3 mode (GAN.py:102-107 / :135-140, layers 2-4): the space-to-depth operands in PACKED form without their fp32 images.
+ * uda_x3_pack_s2d_fwd = uda_s2d_fwd + uda_x3_pack of z (out: uda_x3_packed_bytes(N*Hz*Wz, 4C) bytes); uda_x3_pack_s2d_bwd =
+ * uda_s2d_bwd_gate + uda_x3_pack of the routed gradient (out: uda_x3_packed_bytes(N*Hs*Ws, C) bytes).  C % 8 == 0.  The results
+ * are bit-identical to the two-pass forms (the split is exact); one read of the source and one packed write instead of a read,
+ * an fp32 write, an fp32 read and the packed write. */
+int uda_x3_pack_s2d_fwd(const float* src, int64_t ld_src, int N, int Hs, int Ws, int C, int valid_h, int valid_w, float slope,
+                        int Hz, int Wz, void* out, void* stream);
+int uda_x3_pack_s2d_bwd(const float* dz, int64_t ld_z, int Hz, int Wz, const float* gate_rows, int64_t ld_gate, float slope,
+                        int N, int Hs, int Ws, int C, int valid_h, int valid_w, void* out, void* stream);
 
 /* ---- batch-norm pieces (F.batch_norm, training and eval) */
 /* stats: double[UDA_STAT_SLOTS][2][C] */

@@ -775,6 +775,48 @@ CASES += [
 ]
 
 
+def case_s2d_packed(N, H, W, C, vh=None, vw=None, seed=22):
+    """bf16x3 mode: the packed space-to-depth operands written in ONE pass (uda_x3_pack_s2d_fwd / _bwd, round 3) are bit-identical
+    to the two-pass forms they replace (uda_s2d_fwd / uda_s2d_bwd + uda_x3_pack: the split is exact), and the gate read from the
+    sign of the forward's source rows equals the gate read from the sign of z = lrelu(source)."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        vh_, vw_ = vh or H, vw or W
+        Hz, Wz = (vh_ + 5) // 2, (vw_ + 5) // 2
+        src = to_dev(padded(N * H * W, C, g), dev)
+        src[::7] = 0.0                                   # exact zeros: lrelu(0) = 0 is "not positive" for both kinds of gate
+        z = to_dev(padded(N * Hz * Wz, 4 * C, g), dev)
+        K.s2d_fwd(src, False, N, H, W, C, vh_, vw_, 0.2, z)
+        za = Act(z, N, Hz, Wz)
+        want = K.x3_pack(K._src(za), za.P, za.C, dev)
+        got = K.s2d_pack_fwd(src, N, H, W, C, vh_, vw_, 0.2)
+        bad = int((got._x3 != want).sum())
+        dz = to_dev(padded(N * Hz * Wz, 4 * C, g), dev)
+        d_z, d_g = to_dev(padded(N * H * W, C, g), dev), to_dev(padded(N * H * W, C, g), dev)
+        K.s2d_bwd(dz, z, 0.2, N, H, W, C, vh_, vw_, d_z, False)
+        K.s2d_bwd(dz, None, 0.2, N, H, W, C, vh_, vw_, d_g, False, gate=src)
+        bad += int((d_z != d_g).sum())
+        da = Act(d_g, N, H, W)
+        want_b = K.x3_pack(K._src(da), da.P, da.C, dev)
+        got_b = K.s2d_pack_bwd(dz, src, 0.2, N, H, W, C, vh_, vw_)
+        bad += int((got_b._x3 != want_b).sum())
+        got_n = K.s2d_pack_bwd(dz, None, 0.2, N, H, W, C, vh_, vw_)          # no gate (slope irrelevant)
+        K.s2d_bwd(dz, None, 1.0, N, H, W, C, vh_, vw_, d_z, False)
+        dn = Act(d_z, N, H, W)
+        bad += int((got_n._x3 != K.x3_pack(K._src(dn), dn.P, dn.C, dev)).sum())
+        return float(bad), 0.0
+    return run
+
+
+CASES += [
+    ("s2d packed C=64 grid 18x18 valid 17x17", case_s2d_packed(2, 18, 18, 64, 17, 17)),
+    ("s2d packed C=128 grid 35x35 valid 33x33", case_s2d_packed(3, 35, 35, 128, 33, 33)),
+    ("s2d packed C=8 grid 11x9 valid 9x8 (half-filled 16-blocks)", case_s2d_packed(1, 11, 9, 8, 9, 8)),
+    ("s2d packed C=72 grid 10x12 (4C = 288, ragged tiles)", case_s2d_packed(2, 10, 12, 72)),
+]
+
+
 def case_relayout_s2d(O, C, seed=21):
     def run(dev):
         w = torch.randn(O, C, 4, 4, generator=gen(seed))

@@ -525,8 +525,8 @@ def test_resnet101_per_gpu_batch_8_at_512_properties():
     (o0, g0, r0), (o1, g1, r1) = runs
     assert all(bool(torch.isfinite(v).all()) for v in g0.values()) and len(g0) == len(list(m.parameters()))
     assert model_cases.rel(o1, o0[perm]) < 2e-4
-    for k in r0:
-        assert model_cases.rel(r1[k], r0[k]) < 1e-5, k
+    for k in r0:      # (two summation orders of the batch sums below 101 BN layers: measured 5e-5 at the ASPP, 1e-5 holds for MobileNetV2)
+        assert model_cases.rel(r1[k], r0[k]) < 3e-4, k
     # two summation orders of the same batch sums through 101 layers of training-mode BN (the BN-affine gradients are
     # near-cancelling sums): the median tensor agrees to 1e-4, the worst to a few 1e-3
     errs = sorted((model_cases.l2rel(g1[k], g0[k]), k) for k in g0)

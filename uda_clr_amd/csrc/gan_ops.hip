@@ -22,6 +22,10 @@ struct S2dArgs {
     // derivative at the logits `pre_x` (NCHW, the forward's source).
     int pre_op;
     const float* pre_x;
+    // backward, alternative gate: rows [N, Hs, Ws, C] of the forward's SOURCE (z = lrelu(source), so the signs agree) - used when
+    // the fp32 z image was never written (bf16x3 mode packs it straight from the source, uda_x3_pack_s2d_fwd)
+    const float* gate;
+    int64_t ld_gate;
 };
 
 #define ADV_SMOOTH 1e-7f
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256) void s2d_bwd_kernel(S2dArgs p) {
             const int q = ((((h + 2) & 1) << 1) | ((w + 2) & 1)) * p.C + c;
             g = p.src[pz * p.ld_src + q];
             if (p.zsign && !(p.zsign[pz * p.ld_src + q] > 0.f)) g *= p.slope;
+            if (p.gate && !(p.gate[(((int64_t)n * p.Hs + h) * p.Ws + w) * p.ld_gate + c] > 0.f)) g *= p.slope;
             if (p.pre_op) g *= adv_pre_grad(p.pre_x[e], p.pre_op);        // nchw only (checked by the entry point): e indexes the logits
         }
         if (p.nchw) p.dst[e] = g;
@@ -123,6 +128,13 @@ __global__ __launch_bounds__(256) void s2d_bwd4_kernel(S2dArgs p) {
                 if (!(z.z > 0.f)) g.z *= p.slope;
                 if (!(z.w > 0.f)) g.w *= p.slope;
             }
+            if (p.gate) {
+                const float4 z = uda_ld4(p.gate + (((int64_t)n * p.Hs + h) * p.Ws + w) * p.ld_gate + c);
+                if (!(z.x > 0.f)) g.x *= p.slope;
+                if (!(z.y > 0.f)) g.y *= p.slope;
+                if (!(z.z > 0.f)) g.z *= p.slope;
+                if (!(z.w > 0.f)) g.w *= p.slope;
+            }
         }
         uda_st4(p.dst + (((int64_t)n * p.Hs + h) * p.Ws + w) * p.ld_dst + c, g);
     }
@@ -139,7 +151,7 @@ extern "C" int uda_s2d_fwd(const float* src, int64_t ld_src, int nchw_in, int N,
                            float slope, float* z, int64_t ld_z, int Hz, int Wz, void* stream) {
     if (int e = s2d_check("uda_s2d_fwd", src, z, N, Hs, Ws, C, valid_h, valid_w, Hz, Wz)) return e;
     UDA_REQUIRE(ld_z >= 4 * C && (nchw_in || ld_src >= C), "uda_s2d_fwd: leading dimensions too small");
-    S2dArgs p;
+    S2dArgs p = {};
     p.src = src; p.ld_src = ld_src; p.zsign = nullptr; p.dst = z; p.ld_dst = ld_z;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.C = C; p.vh = valid_h; p.vw = valid_w; p.Hz = Hz; p.Wz = Wz; p.nchw = nchw_in; p.slope = slope;
     p.pre_op = 0; p.pre_x = nullptr;
@@ -156,7 +168,7 @@ extern "C" int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, i
                            int C, int valid_h, int valid_w, float* dst, int64_t ld_dst, int nchw_out, void* stream) {
     if (int e = s2d_check("uda_s2d_bwd", dz, dst, N, Hs, Ws, C, valid_h, valid_w, Hz, Wz)) return e;
     UDA_REQUIRE(ld_z >= 4 * C && (nchw_out || ld_dst >= C), "uda_s2d_bwd: leading dimensions too small");
-    S2dArgs p;
+    S2dArgs p = {};
     p.src = dz; p.ld_src = ld_z; p.zsign = z_sign; p.dst = dst; p.ld_dst = ld_dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.C = C; p.vh = valid_h; p.vw = valid_w; p.Hz = Hz; p.Wz = Wz; p.nchw = nchw_out; p.slope = slope;
     p.pre_op = 0; p.pre_x = nullptr;
@@ -170,6 +182,26 @@ extern "C" int uda_s2d_bwd(const float* dz, const float* z_sign, int64_t ld_z, i
     return 0;
 }
 
+/* uda_s2d_bwd with the LeakyReLU gate read from the sign of the forward's SOURCE rows [N, Hs, Ws, C] instead of the z image
+ * (same signs: z = lrelu(source)); rows out. */
+extern "C" int uda_s2d_bwd_gate(const float* dz, int64_t ld_z, int Hz, int Wz, const float* gate_rows, int64_t ld_gate, float slope,
+                                int N, int Hs, int Ws, int C, int valid_h, int valid_w, float* dst, int64_t ld_dst, void* stream) {
+    if (int e = s2d_check("uda_s2d_bwd_gate", dz, dst, N, Hs, Ws, C, valid_h, valid_w, Hz, Wz)) return e;
+    UDA_REQUIRE(ld_z >= 4 * C && ld_dst >= C && gate_rows && ld_gate >= C, "uda_s2d_bwd_gate: leading dimensions too small / no gate");
+    S2dArgs p = {};
+    p.src = dz; p.ld_src = ld_z; p.zsign = nullptr; p.dst = dst; p.ld_dst = ld_dst;
+    p.N = N; p.Hs = Hs; p.Ws = Ws; p.C = C; p.vh = valid_h; p.vw = valid_w; p.Hz = Hz; p.Wz = Wz; p.nchw = 0; p.slope = slope;
+    p.pre_op = 0; p.pre_x = nullptr; p.gate = gate_rows; p.ld_gate = ld_gate;
+    const bool v4 = C % 4 == 0 && ld_z % 4 == 0 && ld_dst % 4 == 0 && ld_gate % 4 == 0 && uda_aligned16(dz) && uda_aligned16(dst) &&
+                    uda_aligned16(gate_rows);
+    const int64_t total = (int64_t)N * Hs * Ws * (v4 ? C / 4 : C);
+    const int grid = (int)(uda_cdiv(total, 256) > 16384 ? 16384 : uda_cdiv(total, 256));
+    if (v4) hipLaunchKernelGGL(s2d_bwd4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(s2d_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    UDA_LAUNCH_CHECK("s2d_bwd_gate");
+    return 0;
+}
+
 // First discriminator layer fed by generator logits: z = s2d(pre(logits)) and its adjoint d logits = route(dz) * pre'(logits),
 // pre = sigmoid (boundary branch) or the uncertainty map (Trainer_prototype_full.py:452-454); replaces the elementwise
 // sigmoid / log / mul chain and its autograd backward on the full-resolution maps.
@@ -177,7 +209,7 @@ extern "C" int uda_adv_s2d_fwd(const float* logits_nchw, int N, int C, int H, in
                                void* stream) {
     if (int e = s2d_check("uda_adv_s2d_fwd", logits_nchw, z, N, H, W, C, H, W, Hz, Wz)) return e;
     UDA_REQUIRE(ld_z >= 4 * C && (pre_op == 1 || pre_op == 2), "uda_adv_s2d_fwd: bad leading dimension or pre_op");
-    S2dArgs p;
+    S2dArgs p = {};
     p.src = logits_nchw; p.ld_src = 0; p.zsign = nullptr; p.dst = z; p.ld_dst = ld_z;
     p.N = N; p.Hs = H; p.Ws = W; p.C = C; p.vh = H; p.vw = W; p.Hz = Hz; p.Wz = Wz; p.nchw = 1; p.slope = 1.f;
     p.pre_op = pre_op; p.pre_x = nullptr;
@@ -192,7 +224,7 @@ extern "C" int uda_adv_s2d_bwd(const float* dz, int64_t ld_z, int Hz, int Wz, co
                                int pre_op, float* d_logits_nchw, void* stream) {
     if (int e = s2d_check("uda_adv_s2d_bwd", dz, d_logits_nchw, N, H, W, C, H, W, Hz, Wz)) return e;
     UDA_REQUIRE(ld_z >= 4 * C && logits_nchw && (pre_op == 1 || pre_op == 2), "uda_adv_s2d_bwd: bad args");
-    S2dArgs p;
+    S2dArgs p = {};
     p.src = dz; p.ld_src = ld_z; p.zsign = nullptr; p.dst = d_logits_nchw; p.ld_dst = 0;
     p.N = N; p.Hs = H; p.Ws = W; p.C = C; p.vh = H; p.vw = W; p.Hz = Hz; p.Wz = Wz; p.nchw = 1; p.slope = 1.f;
     p.pre_op = pre_op; p.pre_x = logits_nchw;

@@ -56,6 +56,18 @@ struct X3PackArgs {
     int64_t P;
     int nb;               // 16-wide blocks per row
     uint32_t* out;        // packed, [P][nb][3][16] bf16
+    // XF 3 / 4: the operand is a space-to-depth image of the patch discriminators (gan_ops.hip) that is never written in fp32:
+    //   XF 3 (forward):  row (n, i, j) of the z grid, channel q = (a, b, c):  lrelu(g[n, 2i + a - 2, 2j + b - 2, c]), 0 outside
+    //                    the valid vh x vw region of the previous layer's output g (rows [N, Hs, Ws, Cs]);
+    //   XF 4 (backward): row (n, h, w) of [N, Hs, Ws, Cs], channel c: the routed gradient dz[z slot of (h, w)][(a, b, c)] times
+    //                    the LeakyReLU gate read from the sign of gate[n, h, w, c] (the forward's source), 0 outside vh x vw.
+    // src.C = channels of the packed operand (4 Cs / Cs), P its rows.
+    const float* g;
+    int64_t g_ld;
+    const float* gate;
+    int64_t gate_ld;
+    int Hs, Ws, Cs, vh, vw, Hz, Wz;
+    float slope;
 };
 
 template <int XF>
@@ -71,7 +83,46 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(X3PackArgs a) {
         const int64_t p = p0 + dp;
         const int c0 = o * 8;
         uint32_t q1[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0}, q3[4] = {0, 0, 0, 0};
-        if (e0 + tid < total) {
+        if (XF >= 3 && e0 + tid < total) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (c0 < C) {                                        // (Cs % 8 == 0: an octet never straddles two (a, b) planes)
+                if (XF == 3) {
+                    const int j = (int)(p % a.Wz), i = (int)((p / a.Wz) % a.Hz);
+                    const int64_t n = p / ((int64_t)a.Wz * a.Hz);
+                    const int ab = c0 / a.Cs, c = c0 - ab * a.Cs;
+                    const int hh = 2 * i + (ab >> 1) - 2, ww = 2 * j + (ab & 1) - 2;
+                    if (hh >= 0 && hh < a.vh && ww >= 0 && ww < a.vw) {
+                        const float* r = a.g + ((n * a.Hs + hh) * a.Ws + ww) * a.g_ld + c;
+                        const float4 x0 = uda_ld4(r), x1 = uda_ld4(r + 4);
+                        const float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = t[q] > 0.f ? t[q] : t[q] * a.slope;
+                    }
+                } else {
+                    const int w = (int)(p % a.Ws), hh = (int)((p / a.Ws) % a.Hs);
+                    const int64_t n = p / ((int64_t)a.Ws * a.Hs);
+                    if (hh < a.vh && w < a.vw) {
+                        const int64_t pz = (n * a.Hz + ((hh + 2) >> 1)) * a.Wz + ((w + 2) >> 1);
+                        const int q0 = ((((hh + 2) & 1) << 1) | ((w + 2) & 1)) * a.Cs + c0;
+                        const float* r = a.g + pz * a.g_ld + q0;
+                        const float4 x0 = uda_ld4(r), x1 = uda_ld4(r + 4);
+                        float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        if (a.gate) {
+                            const float* gr = a.gate + p * a.gate_ld + c0;
+                            const float4 g0 = uda_ld4(gr), g1 = uda_ld4(gr + 4);
+                            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (!(gv[q] > 0.f)) t[q] *= a.slope;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = t[q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], q1[j], q2[j], q3[j]);
+        }
+        if (XF < 3 && e0 + tid < total) {
             float v[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -569,7 +620,7 @@ extern "C" int uda_x3_pack(const uda_src_t* src, void* out, void* stream) {
     UDA_REQUIRE(src && src->x && out && uda_aligned16(out) && uda_aligned16(src->x) && src->ldx % 4 == 0 && src->C > 0,
                 "uda_x3_pack: bad args (16-byte aligned rows)");
     hipStream_t st = (hipStream_t)stream;
-    X3PackArgs pa;
+    X3PackArgs pa = {};
     pa.src = *src; pa.P = (int64_t)src->N * src->H * src->W; pa.nb = x3_nb(src->C); pa.out = reinterpret_cast<uint32_t*>(out);
     UDA_REQUIRE(pa.P > 0, "uda_x3_pack: empty operand");
     const int64_t tot = pa.P * pa.nb * 2;
@@ -578,6 +629,47 @@ extern "C" int uda_x3_pack(const uda_src_t* src, void* out, void* stream) {
     else if (src->scale || src->act != ACT_NONE) hipLaunchKernelGGL(x3_pack_kernel<1>, dim3(grid), dim3(256), 0, st, pa);
     else hipLaunchKernelGGL(x3_pack_kernel<0>, dim3(grid), dim3(256), 0, st, pa);
     UDA_LAUNCH_CHECK("x3_pack");
+    return 0;
+}
+
+/* The packed space-to-depth image of a discriminator layer's input, straight from the previous layer's output (rows
+ * [N, Hs, Ws, C], valid region valid_h x valid_w, LeakyReLU(slope) fused): what uda_s2d_fwd + uda_x3_pack would produce, without
+ * the fp32 image in between.  out: [N*Hz*Wz][4C/16][3][16] bf16 (uda_x3_packed_bytes(N*Hz*Wz, 4C)).  C % 8 == 0. */
+extern "C" int uda_x3_pack_s2d_fwd(const float* src, int64_t ld_src, int N, int Hs, int Ws, int C, int valid_h, int valid_w, float slope,
+                                   int Hz, int Wz, void* out, void* stream) {
+    UDA_REQUIRE(src && out && uda_aligned16(src) && uda_aligned16(out) && ld_src % 4 == 0 && ld_src >= C && C > 0 && C % 8 == 0,
+                "uda_x3_pack_s2d_fwd: bad args (C %% 8 == 0, 16-byte aligned rows)");
+    UDA_REQUIRE(N > 0 && valid_h > 0 && valid_w > 0 && valid_h <= Hs && valid_w <= Ws && Hz == (valid_h + 5) / 2 && Wz == (valid_w + 5) / 2,
+                "uda_x3_pack_s2d_fwd: bad geometry");
+    X3PackArgs pa = {};
+    pa.src.C = 4 * C; pa.P = (int64_t)N * Hz * Wz; pa.nb = x3_nb(4 * C); pa.out = reinterpret_cast<uint32_t*>(out);
+    pa.g = src; pa.g_ld = ld_src; pa.gate = nullptr; pa.gate_ld = 0;
+    pa.Hs = Hs; pa.Ws = Ws; pa.Cs = C; pa.vh = valid_h; pa.vw = valid_w; pa.Hz = Hz; pa.Wz = Wz; pa.slope = slope;
+    const int64_t tot = pa.P * pa.nb * 2;
+    const int grid = (int)(uda_cdiv(tot, 256) > 65536 ? 65536 : uda_cdiv(tot, 256));
+    hipLaunchKernelGGL(x3_pack_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pa);
+    UDA_LAUNCH_CHECK("x3_pack_s2d_fwd");
+    return 0;
+}
+
+/* The packed gradient w.r.t. a discriminator layer's INPUT rows [N, Hs, Ws, C] from dz (rows on the z grid, 4C channels): what
+ * uda_s2d_bwd + uda_x3_pack would produce.  gate_rows ([N, Hs, Ws, C], may be null): the forward's source, whose sign is the
+ * LeakyReLU gate.  out: uda_x3_packed_bytes(N*Hs*Ws, C).  C % 8 == 0. */
+extern "C" int uda_x3_pack_s2d_bwd(const float* dz, int64_t ld_z, int Hz, int Wz, const float* gate_rows, int64_t ld_gate, float slope,
+                                   int N, int Hs, int Ws, int C, int valid_h, int valid_w, void* out, void* stream) {
+    UDA_REQUIRE(dz && out && uda_aligned16(dz) && uda_aligned16(out) && ld_z % 4 == 0 && ld_z >= 4 * C && C > 0 && C % 8 == 0,
+                "uda_x3_pack_s2d_bwd: bad args (C %% 8 == 0, 16-byte aligned rows)");
+    UDA_REQUIRE(!gate_rows || (uda_aligned16(gate_rows) && ld_gate % 4 == 0 && ld_gate >= C), "uda_x3_pack_s2d_bwd: bad gate rows");
+    UDA_REQUIRE(N > 0 && valid_h > 0 && valid_w > 0 && valid_h <= Hs && valid_w <= Ws && Hz == (valid_h + 5) / 2 && Wz == (valid_w + 5) / 2,
+                "uda_x3_pack_s2d_bwd: bad geometry");
+    X3PackArgs pa = {};
+    pa.src.C = C; pa.P = (int64_t)N * Hs * Ws; pa.nb = x3_nb(C); pa.out = reinterpret_cast<uint32_t*>(out);
+    pa.g = dz; pa.g_ld = ld_z; pa.gate = gate_rows; pa.gate_ld = ld_gate;
+    pa.Hs = Hs; pa.Ws = Ws; pa.Cs = C; pa.vh = valid_h; pa.vw = valid_w; pa.Hz = Hz; pa.Wz = Wz; pa.slope = slope;
+    const int64_t tot = pa.P * pa.nb * 2;
+    const int grid = (int)(uda_cdiv(tot, 256) > 65536 ? 65536 : uda_cdiv(tot, 256));
+    hipLaunchKernelGGL(x3_pack_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pa);
+    UDA_LAUNCH_CHECK("x3_pack_s2d_bwd");
     return 0;
 }
 

@@ -11,11 +11,14 @@ lives on its own z grid with Ho = H // 2 + 1 valid rows/columns (257, 129, 65, 3
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .acts import Act, round4
 
 SLOPE = 0.2
+_S2D_PACK = os.environ.get("UDA_CLR_S2D_PACK", "1") != "0"      # A/B switch of the one-pass packed space-to-depth operands
 
 
 def _zgrid(v):
@@ -52,14 +55,25 @@ class PatchDiscriminatorEngine:
                         w_share[(li, 1)] = K.relayout_s2d(w, True)
                     wd = w_share[(li, 1)]
             Hz, Wz = _zgrid(vh), _zgrid(vw)
-            z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
-            if li == 0 and pre_op:
-                K.adv_s2d_fwd(src, pre_op, z)
+            # bf16x3 mode, layers whose conv (and weight gradient) run on the packed operands: the z image is written in packed form
+            # only, straight from the previous layer's output (uda_x3_pack_s2d_fwd) - no fp32 image, no separate packing pass; the
+            # backward then takes the LeakyReLU gate from the sign of that source (z = lrelu(source)), which is kept instead
+            packed = (li > 0 and Cc % 8 == 0 and hasattr(K, "s2d_pack_fwd") and _S2D_PACK and K.conv_route_x3(N, Hz, Wz, 4 * Cc, O, 2)
+                      and (not need_grad or K.wgrad_route_x3(N, Hz, Wz, 4 * Cc, O, 2)))
+            if packed:
+                z = K.s2d_pack_fwd(src, N, Hs, Ws, Cc, vh, vw, slope)
             else:
-                K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
+                z = torch.empty((N * Hz * Wz, 4 * Cc), dtype=torch.float32, device=x.device)
+                if li == 0 and pre_op:
+                    K.adv_s2d_fwd(src, pre_op, z)
+                else:
+                    K.s2d_fwd(src, nchw, N, Hs, Ws, Cc, vh, vw, slope, z)
             y = torch.empty((N * Hz * Wz, round4(O)), dtype=torch.float32, device=x.device)[:, :O]
             K.conv(Act(z, N, Hz, Wz), wf, 2, 1, y, origin=0)
-            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd))
+            # (bf16x3 mode keeps the source rows of every layer but the first as the backward's gate: the gradient below a layer
+            # can then be written in packed form whether or not this layer's own z image was)
+            keep_gate = need_grad and li > 0 and (packed or getattr(K, "mfma", None) == getattr(K, "MFMA_BF16X3", -1))
+            layers.append((z if need_grad else None, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd, src if keep_gate else None))
             src, nchw, Hs, Ws, Cc, slope = y, False, Hz, Wz, O, SLOPE
             vh, vw = vh // 2 + 1, vw // 2 + 1
         out = src.reshape(N, Hs, Ws, Cc)[:, :vh, :vw].permute(0, 3, 1, 2)
@@ -69,7 +83,7 @@ class PatchDiscriminatorEngine:
         """gout: gradient of the [N, 1, Ho, Wo] logits.  Returns (dx NCHW or None, [dw OIHW 4x4] or None)."""
         K = self.K
         layers, N, xshape, x_logits, pre_op = ctx
-        z5, C5, Hs5, Ws5, vh5, vw5, Hz, Wz, _, _ = layers[-1]
+        z5, C5, Hs5, Ws5, vh5, vw5, Hz, Wz, _, _, _ = layers[-1]
         O = weights[-1].shape[0]
         vh, vw = vh5 // 2 + 1, vw5 // 2 + 1
         dy = torch.zeros((N, Hz, Wz, round4(O)), dtype=torch.float32, device=gout.device)
@@ -78,7 +92,7 @@ class PatchDiscriminatorEngine:
         dws = [None] * len(weights)
         dx = None
         for l in range(len(weights) - 1, -1, -1):
-            z, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd = layers[l]
+            z, Cc, Hs, Ws, vh, vw, Hz, Wz, nchw, wd, gate = layers[l]
             w = weights[l]
             O = w.shape[0]
             if need_w:
@@ -91,14 +105,27 @@ class PatchDiscriminatorEngine:
             dz = torch.empty_like(z)
             K.conv(Act(dy, N, Hz, Wz), wd, 2, 1, dz, origin=1)
             if nchw:
-                dx = torch.empty(xshape, dtype=torch.float32, device=z.device)
+                dx = torch.empty(xshape, dtype=torch.float32, device=dz.device)
                 if pre_op:
                     K.adv_s2d_bwd(dz, x_logits, pre_op, dx)
                 else:
                     K.s2d_bwd(dz, None, 1.0, N, Hs, Ws, Cc, vh, vw, dx, True)
             else:
-                dyn = torch.empty((N * Hs * Ws, round4(Cc)), dtype=torch.float32, device=z.device)[:, :Cc]
-                K.s2d_bwd(dz, z, SLOPE, N, Hs, Ws, Cc, vh, vw, dyn, False)
-                dy = dyn
+                # the gradient w.r.t. layer l-1's output: read by that layer's weight gradient and input-gradient conv.  When both run
+                # on packed operands it is written in packed form only (uda_x3_pack_s2d_bwd)
+                below = layers[l - 1]
+                need_dx_below = (l - 1 > 0) or need_x
+                pack_dy = (gate is not None and hasattr(K, "s2d_pack_bwd") and _S2D_PACK and Cc % 8 == 0
+                           and (not need_w or K.wgrad_route_x3(N, Hs, Ws, 4 * below[1], Cc, 2))
+                           and (not need_dx_below or K.conv_route_x3(N, Hs, Ws, Cc, 4 * below[1], 2)))
+                if pack_dy:
+                    dy = K.s2d_pack_bwd(dz, gate, SLOPE, N, Hs, Ws, Cc, vh, vw)
+                else:
+                    dyn = torch.empty((N * Hs * Ws, round4(Cc)), dtype=torch.float32, device=dz.device)[:, :Cc]
+                    if gate is not None:
+                        K.s2d_bwd(dz, None, SLOPE, N, Hs, Ws, Cc, vh, vw, dyn, False, gate=gate)
+                    else:
+                        K.s2d_bwd(dz, z, SLOPE, N, Hs, Ws, Cc, vh, vw, dyn, False)
+                    dy = dyn
             del dz
         return dx, (dws if need_w else None)

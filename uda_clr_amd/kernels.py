@@ -76,6 +76,9 @@ SYMBOLS = {
     "uda_relayout_s2d": (_I, [_P, _I, _I, _I, _P, _P]),
     "uda_s2d_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _I, _I, _P]),
     "uda_s2d_bwd": (_I, [_P, _P, _L, _I, _I, _F, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
+    "uda_s2d_bwd_gate": (_I, [_P, _L, _I, _I, _P, _L, _F, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "uda_x3_pack_s2d_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P]),
+    "uda_x3_pack_s2d_bwd": (_I, [_P, _L, _I, _I, _P, _L, _F, _I, _I, _I, _I, _I, _I, _P, _P]),
     "uda_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "uda_bn_running_replay": (_I, [_P, _P, _I, _D, _I, _F, _F, _P, _P, _P]),
     "uda_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
@@ -504,10 +507,69 @@ class HipKernels:
         zp, ldz = _mat(z, "z")
         self._ck(self.lib.uda_s2d_fwd(sp, lds_, int(nchw), N, Hs, Ws, Cc, vh, vw, float(slope), zp, ldz, Hz, Wz, self._stream()))
 
-    def s2d_bwd(self, dz, z_sign, slope, N, Hs, Ws, Cc, vh, vw, dst, nchw):
+    # ---- bf16x3: space-to-depth operands in packed form only (no fp32 image); the engine asks the routing predicates first
+    def conv_route_x3(self, N, H, W, Cin, Cout, ksize):
+        """True when ``conv`` of a RAW [N*H*W, Cin] operand to Cout outputs runs on the bf16x3 kernel in one launch."""
+        if self.mfma != self.MFMA_BF16X3 or self._image_groups(N, H * W, max(round4(Cin), round4(Cout)), Cin) is not None:
+            return False
+        a = UdaConvArgs()
+        a.src.N, a.src.H, a.src.W, a.src.C = N, H, W, Cin
+        a.src.scale = a.src.shift = a.src.mask = None
+        a.src.act, a.Cout, a.ksize, a.dil, a.mfma = 0, Cout, ksize, 1, self.mfma
+        a.stats = None
+        return bool(self.lib.uda_conv_uses_x3(C.byref(a)))
+
+    def wgrad_route_x3(self, N, H, W, Cin, Cout, ksize):
+        """True when ``conv_wgrad`` of a raw [N*H*W, Cin] source against a [N*H*W, Cout] gradient runs on the bf16x3 kernel."""
+        if self.mfma != self.MFMA_BF16X3 or self._image_groups(N, H * W, max(round4(Cin), round4(Cout))) is not None:
+            return False
+        a = UdaWgradArgs()
+        a.src.N, a.src.H, a.src.W, a.src.C = N, H, W, Cin
+        a.src.scale = a.src.shift = a.src.mask = None
+        a.src.act, a.Cout, a.ksize, a.dil, a.mfma = 0, Cout, ksize, 1, self.mfma
+        return bool(self.lib.uda_conv_wgrad_uses_x3(C.byref(a)))
+
+    def _packed_only(self, rows, Cc, device):
+        """A [rows, Cc] fp32 matrix that exists ONLY in packed bf16x3 form: the returned tensor is an (uninitialised, never
+        read) fp32 view over the head of the packed buffer, which rides on it as ``_x3`` like any cached packed operand -
+        the x3 conv / weight-gradient kernels read nothing else.  Returns (matrix, packed bytes)."""
+        xs = torch.empty(int(self.lib.uda_x3_packed_bytes(rows, Cc)), dtype=torch.uint8, device=device)
+        m = xs[:rows * Cc * 4].view(torch.float32).view(rows, Cc)
+        m._x3 = xs
+        return m, xs
+
+    def s2d_pack_fwd(self, src, N, Hs, Ws, Cc, vh, vw, slope):
+        """uda_s2d_fwd + uda_x3_pack in one pass: src rows [N*Hs*Ws, Cc] -> the packed z image (a packed-only matrix
+        [N*Hz*Wz, 4*Cc], see ``_packed_only``)."""
+        self._dev(src)
+        Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
+        assert src.shape == (N * Hs * Ws, Cc) and Cc % 8 == 0
+        sp, lds_ = _mat(src, "src")
+        z, xs = self._packed_only(N * Hz * Wz, 4 * Cc, src.device)
+        self._ck(self.lib.uda_x3_pack_s2d_fwd(sp, lds_, N, Hs, Ws, Cc, vh, vw, float(slope), Hz, Wz, xs.data_ptr(), self._stream()))
+        return z
+
+    def s2d_pack_bwd(self, dz, gate, slope, N, Hs, Ws, Cc, vh, vw):
+        """uda_s2d_bwd_gate + uda_x3_pack in one pass: the packed-only gradient matrix [N*Hs*Ws, Cc]."""
+        Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
+        assert dz.shape == (N * Hz * Wz, 4 * Cc) and Cc % 8 == 0 and (gate is None or gate.shape == (N * Hs * Ws, Cc))
+        gp, ldz = _mat(dz, "dz")
+        tp, ldt = (None, 0) if gate is None else _mat(gate, "gate")
+        d, xs = self._packed_only(N * Hs * Ws, Cc, dz.device)
+        self._ck(self.lib.uda_x3_pack_s2d_bwd(gp, ldz, Hz, Wz, tp, ldt, float(slope), N, Hs, Ws, Cc, vh, vw, xs.data_ptr(), self._stream()))
+        return d
+
+    def s2d_bwd(self, dz, z_sign, slope, N, Hs, Ws, Cc, vh, vw, dst, nchw, gate=None):
+        """``gate``: rows [N*Hs*Ws, Cc] of the forward's source whose sign is the LeakyReLU gate (instead of z_sign)."""
         Hz, Wz = (vh + 5) // 2, (vw + 5) // 2
         assert dz.shape == (N * Hz * Wz, 4 * Cc) and (z_sign is None or (z_sign.shape == dz.shape and z_sign.stride(0) == dz.stride(0)))
         gp, ldz = _mat(dz, "dz")
+        if gate is not None:
+            assert z_sign is None and not nchw and gate.shape == (N * Hs * Ws, Cc) and dst.shape == (N * Hs * Ws, Cc)
+            tp, ldt = _mat(gate, "gate")
+            dp, ldd = _mat(dst, "dst")
+            self._ck(self.lib.uda_s2d_bwd_gate(gp, ldz, Hz, Wz, tp, ldt, float(slope), N, Hs, Ws, Cc, vh, vw, dp, ldd, self._stream()))
+            return
         if nchw:
             assert dst.is_contiguous() and tuple(dst.shape) == (N, Cc, Hs, Ws)
             dp, ldd = dst.data_ptr(), 0

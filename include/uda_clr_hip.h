@@ -223,6 +223,10 @@ int uda_bn_apply(const uda_src_t* src, const float* residual, int64_t ldr, float
                  void* stream);
 /* out (double[UDA_STAT_SLOTS][nq][C], ADDED into): nq=1 sum, nq=2 sum and sum of squares of x */
 int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, void* stream);
+/* the same into a channel WINDOW of a wider accumulator double[UDA_STAT_SLOTS][nq][out_C]: out points at the window's first
+ * channel (slot 0, quantity 0).  The statistics of decoder.py:23's BatchNorm(305) over cat(up(x), low-level, boundary) are
+ * gathered this way: the upsampled channels by uda_upsample_fwd_stats, the other 49 by one window pass. */
+int uda_colstats_window(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, int out_C, void* stream);
 /* g = dU*mask*act'(a);  sums (double[UDA_STAT_SLOTS][3][C], ADDED into) = (sum g, sum g*xhat, sum dU) */
 int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
                      const float* invstd, double* sums, void* stream);
@@ -241,6 +245,10 @@ int uda_bnbwd_apply(const float* dU, int64_t ldu, const uda_src_t* y, const floa
 /* ---- resampling / pooling (F.interpolate bilinear align_corners=True, adaptive_avg_pool2d) */
 int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, float* out,
                      int64_t ldo, int H, int W, void* stream);
+/* uda_upsample_fwd + per-channel (sum, sum of squares) of the output ADDED into channels [0, C) of
+ * stats = double[UDA_STAT_SLOTS][2][stat_C]; needs 256 % (C / 4) == 0 */
+int uda_upsample_fwd_stats(const float* x, int64_t ldx, int N, int h, int w, int C, float* out, int64_t ldo, int H, int W,
+                           double* stats, int stat_C, void* stream);
 int uda_upsample_bwd(const float* dout, int64_t ldo, int N, int H, int W, int C, float* dx,
                      int64_t ldx, int h, int w, void* stream);
 /* NHWC [N*h*w, C<=4] -> contiguous NCHW [N][C][H][W] and its adjoint */

@@ -313,6 +313,29 @@ def case_bn(P, C, q1=False, mask=False, training=True, seed=5, frozen=False):
     return run
 
 
+def case_upsample_stats(N, h, w, H, W, C, Cs, seed=8):
+    """uda_upsample_fwd_stats: the upsampled tensor AND its per-channel (sum, sum of squares) in channels [0, C) of a wider
+    accumulator; uda_colstats_window: the remaining channels of the wide buffer (a strided column window) into the same accumulator
+    (round 3: the BatchNorm(305) statistics of decoder.py:23 without a pass over the whole 305-channel buffer)."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        x = padded(N * h * w, C, g)
+        wide_r, wide_h = padded(N * H * W, Cs, g), to_dev(padded(N * H * W, Cs, g), dev)
+        wide_r[:, C:] = torch.randn(N * H * W, Cs - C, generator=g)
+        wide_h[:, C:] = wide_r[:, C:].to(dev)
+        st_r = torch.zeros(16, 2, Cs, dtype=torch.float64)
+        st_h = torch.zeros(16, 2, Cs, dtype=torch.float64, device=dev)
+        SPEC.upsample_fwd(x, N, h, w, wide_r[:, :C], H, W, stats=st_r)
+        K.upsample_fwd(to_dev(x, dev), N, h, w, wide_h[:, :C], H, W, stats=st_h)
+        SPEC.colstats_window(wide_r[:, C:], st_r, C)
+        K.colstats_window(wide_h[:, C:], st_h, C)
+        full = torch.zeros(16, 2, Cs, dtype=torch.float64)
+        SPEC.colstats(wide_r, full)                       # the one-pass statement over the whole buffer
+        return max(rel(wide_h, wide_r), rel(st_h.sum(0), st_r.sum(0)), rel(st_h.sum(0), full.sum(0))), 2e-5
+    return run
+
+
 def case_resample(N, h, w, H, W, C, seed=6):
     def run(dev):
         g = gen(seed)
@@ -464,6 +487,8 @@ CASES = [
     # resampling
     ("upsample 4x4->16x16 C=256", case_resample(2, 4, 4, 16, 16, 256)),
     ("upsample 8x6->32x24 C=64", case_resample(1, 8, 6, 32, 24, 64)),
+    ("upsample + stats 8x8->32x32 C=256 into 305 (+ 49-channel window)", case_upsample_stats(2, 8, 8, 32, 32, 256, 305)),
+    ("upsample + stats 5x7->20x28 C=64 into 72 (+ 8-channel window)", case_upsample_stats(3, 5, 7, 20, 28, 64, 72)),
     ("head 16x16->64x64 C=2", case_head(2, 16, 16, 64, 64, 2)),
     ("head 12x10->48x40 C=1", case_head(1, 12, 10, 48, 40, 1)),
     ("gap C=320", case_gap(3, 64, 320)),

@@ -349,6 +349,12 @@ class SpecKernels:
         if stats.shape[1] > 1:
             stats[0, 1] += (x.double() ** 2).sum(0)
 
+    def colstats_window(self, x, stats, c_off):
+        Cc = x.shape[1]
+        stats[0, 0, c_off:c_off + Cc] += x.double().sum(0)
+        if stats.shape[1] > 1:
+            stats[0, 1, c_off:c_off + Cc] += (x.double() ** 2).sum(0)
+
     def bnbwd_reduce(self, dU, y: Act, sums):
         """y carries (x, scale, shift, act, mask, bn.mean/invstd).  g = dU * mask*ms * act'(a);
         sums (fp64 [3, C]) = (sum g, sum g*xhat, sum dU)."""
@@ -401,13 +407,16 @@ class SpecKernels:
         out.copy_(g)
 
     # ------------------------------------------------------------------ resampling / pooling
-    def upsample_fwd(self, x, N, h, w, out, H, W):
-        """Bilinear align_corners=True, NHWC [N*h*w, C] -> NHWC [N*H*W, C]."""
+    def upsample_fwd(self, x, N, h, w, out, H, W, stats=None):
+        """Bilinear align_corners=True, NHWC [N*h*w, C] -> NHWC [N*H*W, C]; ``stats``: the output's per-channel (sum, sum of
+        squares) ADDED into channels [0, C) of the fp64 [SLOTS, 2, Cs] accumulator."""
         mh, mw = _bilinear_matrix(h, H, x.device, x.dtype), _bilinear_matrix(w, W, x.device, x.dtype)
         t = x.reshape(N, h, w, -1)
         t = torch.einsum("Hh,nhwc->nHwc", mh, t)
         t = torch.einsum("Ww,nHwc->nHWc", mw, t)
         out.copy_(t.reshape(N * H * W, -1))
+        if stats is not None:
+            self.colstats_window(out, stats, 0)
 
     def upsample_bwd(self, dout, N, H, W, dx, h, w):
         mh, mw = _bilinear_matrix(h, H, dout.device, dout.dtype), _bilinear_matrix(w, W, dout.device, dout.dtype)

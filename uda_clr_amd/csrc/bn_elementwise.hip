@@ -344,7 +344,8 @@ struct RedArgs {
     uda_src_t y;         // MODE 1
     const float* mean;
     const float* invstd;
-    double* out;         // [UDA_STAT_SLOTS][nq][C], fp64 atomics
+    double* out;         // [UDA_STAT_SLOTS][nq][outC], fp64 atomics
+    int outC;            // row length of the accumulator (C, or more when x's channels are a window of a wider statistic)
 };
 
 // ITER: pixel strips per workgroup.  32 for the large layers (fewest atomics); 8 when 32 would leave fewer than ~2 workgroups per
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
         const int q = e / Cb, c = e % Cb;
         float t = 0.f;
         for (int p = 0; p < PP; ++p) t += red[(q * PP + p) * Cp + c];
-        atomicAdd(&a.out[((int64_t)(blockIdx.x % UDA_STAT_SLOTS) * a.nq + q) * a.C + cblk0 + c], (double)t);
+        atomicAdd(&a.out[((int64_t)(blockIdx.x % UDA_STAT_SLOTS) * a.nq + q) * a.outC + cblk0 + c], (double)t);
     }
 }
 
@@ -431,12 +432,19 @@ static inline bool red_short(int64_t P, int C) {
     return (int64_t)red_nwg(P, C, RED_ITER) * uda_cdiv(C, RED_CBLK_SUM) < thr;
 }
 
+extern "C" int uda_colstats_window(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, int out_C, void* stream);
 extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, void* stream) {
+    return uda_colstats_window(x, ldx, P, C, nq, out, C, stream);
+}
+
+/* uda_colstats into a channel WINDOW of a wider accumulator: out points at the window's first channel of slot 0 / quantity 0,
+ * rows of the accumulator are out_C doubles long (double[UDA_STAT_SLOTS][nq][out_C]). */
+extern "C" int uda_colstats_window(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, int out_C, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    UDA_REQUIRE(x && uda_aligned16(x) && ldx % 4 == 0 && ldx >= ((C + 3) / 4) * 4 && P > 0 && C > 0 && (nq == 1 || nq == 2) && out,
-                "uda_colstats: bad args");
+    UDA_REQUIRE(x && uda_aligned16(x) && ldx % 4 == 0 && ldx >= ((C + 3) / 4) * 4 && P > 0 && C > 0 && (nq == 1 || nq == 2) && out &&
+                    out_C >= C, "uda_colstats: bad args");
     RedArgs a;
-    a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.out = out;
+    a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.out = out; a.outC = out_C;
     if (red_short(P, C))
         hipLaunchKernelGGL((colreduce_kernel<0, 8>), dim3(red_nwg(P, C, 8), uda_cdiv(C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     else
@@ -453,7 +461,7 @@ extern "C" int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y
     UDA_REQUIRE(dU && uda_aligned16(dU) && ldu % 4 == 0 && ldu >= ((y->C + 3) / 4) * 4, "uda_bnbwd_reduce: bad dU layout");
     const int64_t P = (int64_t)y->N * y->H * y->W;
     RedArgs a;
-    a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.out = sums;
+    a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.out = sums; a.outC = y->C;
     if (red_short(P, y->C))
         hipLaunchKernelGGL((colreduce_kernel<1, 8>), dim3(red_nwg(P, y->C, 8), uda_cdiv(y->C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     else

@@ -8,11 +8,16 @@
 #include "common.h"
 #include "bilinear.h"
 
+// STATS: per-channel (sum, sum of squares) of the OUTPUT accumulated on the way (a thread's channel group is fixed over its
+// grid-stride iterations because 256 % (C / 4) == 0; the host checks it): per-thread fp32 partial sums, the 256 / G threads of a
+// channel group combined through LDS, then fp64 atomics into one of the UDA_STAT_SLOTS replicas of double[2][stat_C].
+template <bool STATS>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int h, int w,
                                                            int C, float* __restrict__ out, int64_t ldo, int H, int W,
-                                                           float sh, float sw) {
+                                                           float sh, float sw, double* __restrict__ stats, int stat_C) {
     const int G = C >> 2;
     const int64_t total = (int64_t)N * H * W * G;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(e % G);
         const int64_t p = e / G;
@@ -30,6 +35,27 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         r.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
         r.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
         uda_st4(out + p * ldo + cg * 4, r);
+        if (STATS) {
+            s1[0] += r.x; s1[1] += r.y; s1[2] += r.z; s1[3] += r.w;
+            s2[0] += r.x * r.x; s2[1] += r.y * r.y; s2[2] += r.z * r.z; s2[3] += r.w * r.w;
+        }
+    }
+    if (STATS) {
+        __shared__ float red[256 * 8];
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[tid * 8 + j] = s1[j];
+            red[tid * 8 + 4 + j] = s2[j];
+        }
+        __syncthreads();
+        // channel c = 4 * cg + j belongs to the threads tid = cg, cg + G, ... (cg = tid % G for every iteration of a thread)
+        for (int e = tid; e < 2 * C; e += 256) {
+            const int q = e / C, c = e - q * C, cg = c >> 2, j = c & 3;
+            float t = 0.f;
+            for (int th = cg; th < 256; th += G) t += red[th * 8 + q * 4 + j];
+            atomicAdd(&stats[((int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 2 + q) * stat_C + c], (double)t);
+        }
     }
 }
 
@@ -69,9 +95,27 @@ extern "C" int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w
     const int64_t total = (int64_t)N * H * W * (C / 4);
     int grid = uda_cdiv(total, 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo, H, W,
-                       bil_scale(h, H), bil_scale(w, W));
+    hipLaunchKernelGGL(upsample_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo, H, W,
+                       bil_scale(h, H), bil_scale(w, W), (double*)nullptr, 0);
     UDA_LAUNCH_CHECK("upsample_fwd");
+    return 0;
+}
+
+/* uda_upsample_fwd that also accumulates the per-channel (sum, sum of squares) of its OUTPUT into channels [0, C) of
+ * stats = double[UDA_STAT_SLOTS][2][stat_C] (ADDED into; the BatchNorm(305) of decoder.py:23 over cat(up(x), low, boundary):
+ * the 256 upsampled channels' statistics come from the pass that writes them).  Needs 256 % (C / 4) == 0. */
+extern "C" int uda_upsample_fwd_stats(const float* x, int64_t ldx, int N, int h, int w, int C, float* out, int64_t ldo, int H,
+                                      int W, double* stats, int stat_C, void* stream) {
+    UDA_REQUIRE(x && out && uda_aligned16(x) && uda_aligned16(out) && ldx % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && C > 0 &&
+                    ldx >= C && ldo >= C, "uda_upsample_fwd_stats: C and lds must be multiples of 4, pointers 16-byte aligned");
+    UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "uda_upsample_fwd_stats: bad geometry");
+    UDA_REQUIRE(stats && stat_C >= C && 256 % (C / 4) == 0, "uda_upsample_fwd_stats: needs an accumulator and 256 %% (C / 4) == 0");
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    int grid = uda_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;                 // (fewer, longer threads: one LDS reduction + 2C fp64 atomics per workgroup)
+    hipLaunchKernelGGL(upsample_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo, H, W,
+                       bil_scale(h, H), bil_scale(w, W), stats, stat_C);
+    UDA_LAUNCH_CHECK("upsample_fwd_stats");
     return 0;
 }
 

@@ -97,6 +97,18 @@ class DomainSplit:
         for h, n0, n1 in self._halves(N):
             self.K.colstats(_rows(x, N, n0, n1), stats[h])
 
+    def colstats_window(self, x, stats, c_off, N=None):
+        if stats.dim() == 3:
+            return self.K.colstats_window(x, stats, c_off)
+        for h, n0, n1 in self._halves(N):
+            self.K.colstats_window(_rows(x, N, n0, n1), stats[h], c_off)
+
+    def upsample_fwd(self, x, N, h, w, out, H, W, stats=None):
+        if stats is None or stats.dim() == 3:
+            return self.K.upsample_fwd(x, N, h, w, out, H, W, stats) if stats is not None else self.K.upsample_fwd(x, N, h, w, out, H, W)
+        for hf, n0, n1 in self._halves(N):
+            self.K.upsample_fwd(_rows(x, N, n0, n1), n1 - n0, h, w, _rows(out, N, n0, n1), H, W, stats[hf])
+
     def bn_apply(self, src: Act, out, residual=None):
         if not src.split:
             return self.K.bn_apply(src, out, residual)

@@ -639,7 +639,12 @@ class GeneratorEngine:
             ctx.arena, ctx.nbt = None, []
             return None, ctx
         K.bn_apply(lo, xf[:, 256:304], None)
-        K.upsample_fwd(feature, N, H16, W16, xf[:, 0:256], H4, W4)
+        # statistics of decoder.last_conv's BatchNorm(305) over cat(up(feature), low, boundary) (decoder.py:23,51-53): the 256
+        # upsampled channels' sums come out of the pass that writes them, the other 49 from one window pass below - no pass over
+        # the whole 305-channel buffer
+        st305 = self._stats(ctx, 305, training)
+        fused_up = training and 256 % (feature.shape[1] // 4) == 0
+        K.upsample_fwd(feature, N, H16, W16, xf[:, 0:256], H4, W4, **({"stats": st305} if fused_up else {}))
         xbu = Act(xf[:, :304], N, H4, W4)
         yb1 = self._empty(x, P4, 256)
         st = self._stats(ctx, 256, training)
@@ -655,9 +660,12 @@ class GeneratorEngine:
                           ACT_RELU, m, ms)
         K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1,
                xf[:, 304:305], bias=params["decoder.last_conv_boundary.8.bias"])
-        st = self._stats(ctx, 305, training)
+        st = st305
         if training:
-            K.colstats(xf[:, :305], st, **({"N": N} if self.tn else {}))
+            if fused_up:
+                K.colstats_window(xf[:, 256:305], st, 256, **({"N": N} if self.tn else {}))
+            else:
+                K.colstats(xf[:, :305], st, **({"N": N} if self.tn else {}))
         m, ms = self._mask(x, "decoder.last_conv.2", P4, 305, N, H4, W4, drop_tr, masks)
         sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N, H4, W4, st, P4, training,
                           ACT_RELU, m, ms)
@@ -729,7 +737,9 @@ class GeneratorEngine:
                     self.rng_offset += 1
                 K.bn_apply(Act(fa.x, N, H16, W16, fa.scale, fa.shift, ACT_RELU, m, 1.0 / (1.0 - p05)),
                            feature[r * P16:(r + 1) * P16], None)
-            K.upsample_fwd(feature, N2, H16, W16, xf[:, 0:256], H4, W4)
+            st305 = self._stats(ctx, 305, True)
+            fused_up = 256 % (feature.shape[1] // 4) == 0
+            K.upsample_fwd(feature, N2, H16, W16, xf[:, 0:256], H4, W4, **({"stats": st305} if fused_up else {}))
             xbu = Act(xf[:, :304], N2, H4, W4)
             yb1 = self._empty(x, reps * P4, 256)
             st = self._stats(ctx, 256, True)
@@ -744,8 +754,11 @@ class GeneratorEngine:
             b2 = self._bn_act(ctx, "decoder.last_conv_boundary.5", yb2, N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
             K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1, xf[:, 304:305],
                    bias=params["decoder.last_conv_boundary.8.bias"])
-            st = self._stats(ctx, 305, True)
-            K.colstats(xf[:, :305], st, **({"N": N2} if self.tn else {}))
+            st = st305
+            if fused_up:
+                K.colstats_window(xf[:, 256:305], st, 256, **({"N": N2} if self.tn else {}))
+            else:
+                K.colstats(xf[:, :305], st, **({"N": N2} if self.tn else {}))
             m, ms = self._mask(x, "decoder.last_conv.2", reps * P4, 305, N2, H4, W4, True, mk)
             sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
             x1b = self._buf(x, reps * P4, 2)

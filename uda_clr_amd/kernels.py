@@ -86,6 +86,8 @@ SYMBOLS = {
     "uda_tn_eval_coeffs": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "uda_bn_apply": (_I, [C.POINTER(UdaSrc), _P, _L, _P, _L, _P]),
     "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P]),
+    "uda_colstats_window": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
+    "uda_upsample_fwd_stats": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P, _I, _P]),
     "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P]),
     "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "uda_bnbwd_apply": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
@@ -653,6 +655,15 @@ class HipKernels:
         assert slots == STAT_SLOTS and Cc == x.shape[1] and stats.dtype == torch.float64 and stats.is_contiguous()
         self._ck(self.lib.uda_colstats(p, ld, x.shape[0], Cc, nq, stats.data_ptr(), self._stream()))
 
+    def colstats_window(self, x, stats, c_off):
+        """(sum, sum of squares) of x's channels ADDED into channels [c_off, c_off + C) of the wider accumulator ``stats``."""
+        self._dev(x)
+        p, ld = _mat(x, "x")
+        slots, nq, Cs = stats.shape
+        Cc = x.shape[1]
+        assert slots == STAT_SLOTS and c_off >= 0 and c_off + Cc <= Cs and stats.dtype == torch.float64 and stats.is_contiguous()
+        self._ck(self.lib.uda_colstats_window(p, ld, x.shape[0], Cc, nq, stats.data_ptr() + 8 * c_off, Cs, self._stream()))
+
     def colsum(self, x, out):
         st = torch.zeros(STAT_SLOTS, 1, x.shape[1], dtype=torch.float64, device=x.device)
         self.colstats(x, st)
@@ -684,11 +695,16 @@ class HipKernels:
                                           c1.data_ptr(), c2.data_ptr(), ad, lda, o, ldo, self._stream()))
 
     # ------------------------------------------------------------------ resampling / pooling
-    def upsample_fwd(self, x, N, h, w, out, H, W):
+    def upsample_fwd(self, x, N, h, w, out, H, W, stats=None):
+        """``stats`` (fp64 [SLOTS, 2, Cs >= C]): also ADD the output's per-channel (sum, sum of squares) into its channels [0, C)."""
         self._dev(x)
         p, ld = _mat(x, "x")
         o, ldo = _mat(out, "out")
         assert x.shape[0] == N * h * w and out.shape == (N * H * W, x.shape[1])
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.shape[:2] == (STAT_SLOTS, 2) and stats.shape[2] >= x.shape[1]
+            self._ck(self.lib.uda_upsample_fwd_stats(p, ld, N, h, w, x.shape[1], o, ldo, H, W, stats.data_ptr(), stats.shape[2], self._stream()))
+            return
         self._ck(self.lib.uda_upsample_fwd(p, ld, N, h, w, x.shape[1], o, ldo, H, W, self._stream()))
 
     def upsample_bwd(self, dout, N, H, W, dx, h, w):

@@ -816,7 +816,8 @@ def case_s2d_packed(N, H, W, C, vh=None, vw=None, seed=22):
         za = Act(z, N, Hz, Wz)
         want = K.x3_pack(K._src(za), za.P, za.C, dev)
         got = K.s2d_pack_fwd(src, N, H, W, C, vh_, vw_, 0.2)
-        bad = int((got._x3 != want).sum())
+        body = lambda t, rows, ch: t[:rows * ((ch + 15) // 16) * 96]          # (uda_x3_packed_bytes adds 64 bytes that nobody writes)
+        bad = int((body(got._x3, za.P, za.C) != body(want, za.P, za.C)).sum())
         dz = to_dev(padded(N * Hz * Wz, 4 * C, g), dev)
         d_z, d_g = to_dev(padded(N * H * W, C, g), dev), to_dev(padded(N * H * W, C, g), dev)
         K.s2d_bwd(dz, z, 0.2, N, H, W, C, vh_, vw_, d_z, False)
@@ -825,11 +826,11 @@ def case_s2d_packed(N, H, W, C, vh=None, vw=None, seed=22):
         da = Act(d_g, N, H, W)
         want_b = K.x3_pack(K._src(da), da.P, da.C, dev)
         got_b = K.s2d_pack_bwd(dz, src, 0.2, N, H, W, C, vh_, vw_)
-        bad += int((got_b._x3 != want_b).sum())
+        bad += int((body(got_b._x3, da.P, da.C) != body(want_b, da.P, da.C)).sum())
         got_n = K.s2d_pack_bwd(dz, None, 0.2, N, H, W, C, vh_, vw_)          # no gate (slope irrelevant)
         K.s2d_bwd(dz, None, 1.0, N, H, W, C, vh_, vw_, d_z, False)
         dn = Act(d_z, N, H, W)
-        bad += int((got_n._x3 != K.x3_pack(K._src(dn), dn.P, dn.C, dev)).sum())
+        bad += int((body(got_n._x3, dn.P, dn.C) != body(K.x3_pack(K._src(dn), dn.P, dn.C, dev), dn.P, dn.C)).sum())
         return float(bad), 0.0
     return run
 

@@ -241,6 +241,14 @@ int uda_bnbwd_finalize(const double* sums, int C, double count, int q1_border, i
 int uda_bnbwd_apply(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean,
                     const float* invstd, const float* c1, const float* c2, const float* addend,
                     int64_t ld_add, float* out, int64_t ldo, void* stream);
+/* The same two passes with the upstream gradient in LOW-RANK form dU[p, c] = sum_{o < k} d[p, o] * w[o, c] (k = 1 or 2, w row-major
+ * [k][C]): the input gradient of a 1x1 conv to k outputs - the decoder's heads, decoder.py:32 (305 -> 2) and :41 (256 -> 1) - is
+ * formed inside the passes instead of being written by a conv and read back twice. */
+int uda_bnbwd_reduce_lowrank(const float* d, int64_t ldd, int k, const float* w, const uda_src_t* y, const float* mean,
+                             const float* invstd, double* sums, void* stream);
+int uda_bnbwd_apply_lowrank(const float* d, int64_t ldd, int k, const float* w, const uda_src_t* y, const float* mean,
+                            const float* invstd, const float* c1, const float* c2, const float* addend, int64_t ld_add,
+                            float* out, int64_t ldo, void* stream);
 
 /* ---- resampling / pooling (F.interpolate bilinear align_corners=True, adaptive_avg_pool2d) */
 int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, float* out,

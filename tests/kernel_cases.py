@@ -313,6 +313,52 @@ def case_bn(P, C, q1=False, mask=False, training=True, seed=5, frozen=False):
     return run
 
 
+def case_bnbwd_lowrank(P, C, k, mask, seed=9):
+    """uda_bnbwd_reduce_lowrank / uda_bnbwd_apply_lowrank: the BN-backward passes on an upstream gradient given as the outer product
+    d [P, k] @ w [k, C] (the input gradient of the decoder's 1x1 heads, k = 2 / 1) against (a) the torch statement and (b) the
+    ordinary passes fed the materialised matrix."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        x = padded(P, C, g)
+        sc, sh = 0.5 + torch.rand(C, generator=g), 0.3 * torch.randn(C, generator=g)
+        a0 = x * sc + sh
+        x[a0.abs() < 1e-4] += 0.01
+        mean, istd = 0.1 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+        mb = None
+        if mask:
+            mbuf = torch.zeros(P, round4(C), dtype=torch.uint8)
+            mbuf[:, :C] = (torch.rand(P, C, generator=g) > 0.1).to(torch.uint8)
+            mb = mbuf[:, :C]
+        y = Act(x, 1, 1, P, sc, sh, ACT_RELU, mb, 1.0 / 0.9 if mask else 1.0, BNRec("t", mean, istd, float(P), False))
+        wide = padded(P, 8, g)                                  # d is a column window of a wider matrix, as in the engine
+        d = wide[:, 4:4 + k]
+        w = torch.randn(k, C, generator=g) / C ** 0.5
+        s_r = torch.zeros(16, 3, C, dtype=torch.float64)
+        SPEC.bnbwd_reduce(None, y, s_r, lowrank=(d, w))
+        yh, dh, wh = act_to(y, dev), to_dev(wide, dev)[:, 4:4 + k], w.to(dev)
+        s_h = torch.zeros(16, 3, C, dtype=torch.float64, device=dev)
+        K.bnbwd_reduce(None, yh, s_h, lowrank=(dh, wh))
+        s_m = torch.zeros(16, 3, C, dtype=torch.float64, device=dev)
+        dU = to_dev(padded(P, C, g), dev)
+        dU.copy_(dh @ wh)
+        K.bnbwd_reduce(dU, yh, s_m)
+        errs = [rel(s_h.sum(0), s_r.sum(0)), rel(s_h.sum(0), s_m.sum(0))]
+        gr = torch.empty(4, C)
+        SPEC.bnbwd_finalize(s_r, y, gr[0], gr[1], gr[2], gr[3])
+        gh = gr.to(dev)
+        ad = padded(P, C, g)
+        o_r = padded(P, C, g)
+        SPEC.bnbwd_apply(None, y, gr[0], gr[1], o_r, ad, lowrank=(d, w))
+        adh = to_dev(ad, dev)
+        o_m = to_dev(padded(P, C, g), dev)
+        K.bnbwd_apply(dU, yh, gh[0], gh[1], o_m, adh)
+        K.bnbwd_apply(None, yh, gh[0], gh[1], adh, adh, lowrank=(dh, wh))      # in place over the addend, as the engine does
+        errs += [rel(adh, o_r), rel(adh, o_m)]
+        return max(errs), 3e-5
+    return run
+
+
 def case_upsample_stats(N, h, w, H, W, C, Cs, seed=8):
     """uda_upsample_fwd_stats: the upsampled tensor AND its per-channel (sum, sum of squares) in channels [0, C) of a wider
     accumulator; uda_colstats_window: the remaining channels of the wide buffer (a strided column window) into the same accumulator
@@ -488,6 +534,9 @@ CASES = [
     ("upsample 4x4->16x16 C=256", case_resample(2, 4, 4, 16, 16, 256)),
     ("upsample 8x6->32x24 C=64", case_resample(1, 8, 6, 32, 24, 64)),
     ("upsample + stats 8x8->32x32 C=256 into 305 (+ 49-channel window)", case_upsample_stats(2, 8, 8, 32, 32, 256, 305)),
+    ("bn backward, low-rank dU: C=305 k=2 mask (seg head)", case_bnbwd_lowrank(3000, 305, 2, True)),
+    ("bn backward, low-rank dU: C=256 k=1 mask (boundary head)", case_bnbwd_lowrank(2500, 256, 1, True)),
+    ("bn backward, low-rank dU: C=40 k=2 raw", case_bnbwd_lowrank(777, 40, 2, False)),
     ("upsample + stats 5x7->20x28 C=64 into 72 (+ 8-channel window)", case_upsample_stats(3, 5, 7, 20, 28, 64, 72)),
     ("head 16x16->64x64 C=2", case_head(2, 16, 16, 64, 64, 2)),
     ("head 12x10->48x40 C=1", case_head(1, 12, 10, 48, 40, 1)),

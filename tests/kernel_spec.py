@@ -355,9 +355,11 @@ class SpecKernels:
         if stats.shape[1] > 1:
             stats[0, 1, c_off:c_off + Cc] += (x.double() ** 2).sum(0)
 
-    def bnbwd_reduce(self, dU, y: Act, sums):
+    def bnbwd_reduce(self, dU, y: Act, sums, lowrank=None):
         """y carries (x, scale, shift, act, mask, bn.mean/invstd).  g = dU * mask*ms * act'(a);
-        sums (fp64 [3, C]) = (sum g, sum g*xhat, sum dU)."""
+        sums (fp64 [3, C]) = (sum g, sum g*xhat, sum dU).  ``lowrank`` = (d [P, k], w [k, C]): dU = d @ w."""
+        if lowrank is not None:
+            dU = lowrank[0] @ lowrank[1]
         a = y.x * y.scale + y.shift
         g = dU * _act_grad(a, y.act)
         if y.mask is not None:
@@ -384,8 +386,10 @@ class SpecKernels:
         dgamma.copy_(sgx.float())
         dbeta.copy_(sg.float())
 
-    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None):
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None, lowrank=None):
         """out = addend + scale * (g - c1 - xhat * c2)   (may run in place over dU / addend)."""
+        if lowrank is not None:
+            dU = lowrank[0] @ lowrank[1]
         a = y.x * y.scale + y.shift
         g = dU * _act_grad(a, y.act)
         if y.mask is not None:

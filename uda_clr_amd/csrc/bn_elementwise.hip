@@ -346,6 +346,13 @@ struct RedArgs {
     const float* invstd;
     double* out;         // [UDA_STAT_SLOTS][nq][outC], fp64 atomics
     int outC;            // row length of the accumulator (C, or more when x's channels are a window of a wider statistic)
+    // MODE 1, low-rank upstream gradient: dU[p, c] = sum_o lr_d[p, o] * lr_w[o, c], o < lr_k <= 2 (the input gradient of a 1x1 conv
+    // to one or two outputs - the decoder's heads, decoder.py:32,41 - is an outer product; it is formed here instead of being
+    // written by a conv and read back).  lr_d = null: dU is read from x.
+    const float* lr_d;
+    int64_t lr_ld;
+    int lr_k;
+    const float* lr_w;
 };
 
 // ITER: pixel strips per workgroup.  32 for the large layers (fewest atomics); 8 when 32 would leave fewer than ~2 workgroups per
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
     for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[q][j] = 0.f;
-    float sc[4], sh[4], mu[4], is[4];
+    float sc[4], sh[4], mu[4], is[4], lw[2][4];
     if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -373,6 +380,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
             sh[j] = ok ? a.y.shift[c0 + j] : 0.f;
             mu[j] = ok ? a.mean[c0 + j] : 0.f;
             is[j] = ok ? a.invstd[c0 + j] : 0.f;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) lw[o][j] = (a.lr_d && ok && o < a.lr_k) ? a.lr_w[(int64_t)o * a.C + c0 + j] : 0.f;
         }
     }
     const int64_t base = (int64_t)blockIdx.x * (PP * ITER);
@@ -380,8 +389,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedArgs a) {
     for (int it = 0; it < ITER; ++it) {
         const int64_t p = base + (int64_t)it * PP + pl;
         if (!active || p >= a.P) continue;
-        const float4 xv = uda_ld4(a.x + p * a.ldx + c0);
-        const float v[4] = {xv.x, xv.y, xv.z, xv.w};
+        float v[4];
+        if (MODE == 1 && a.lr_d) {
+            const float d0 = a.lr_d[p * a.lr_ld], d1 = a.lr_k > 1 ? a.lr_d[p * a.lr_ld + 1] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = d0 * lw[0][j] + d1 * lw[1][j];
+        } else {
+            const float4 xv = uda_ld4(a.x + p * a.ldx + c0);
+            v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+        }
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -443,7 +459,7 @@ extern "C" int uda_colstats_window(const float* x, int64_t ldx, int64_t P, int C
     hipStream_t st = (hipStream_t)stream;
     UDA_REQUIRE(x && uda_aligned16(x) && ldx % 4 == 0 && ldx >= ((C + 3) / 4) * 4 && P > 0 && C > 0 && (nq == 1 || nq == 2) && out &&
                     out_C >= C, "uda_colstats: bad args");
-    RedArgs a;
+    RedArgs a = {};
     a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.nq = nq; a.mean = nullptr; a.invstd = nullptr; a.out = out; a.outC = out_C;
     if (red_short(P, C))
         hipLaunchKernelGGL((colreduce_kernel<0, 8>), dim3(red_nwg(P, C, 8), uda_cdiv(C, RED_CBLK_SUM)), dim3(256), 0, st, a);
@@ -453,15 +469,33 @@ extern "C" int uda_colstats_window(const float* x, int64_t ldx, int64_t P, int C
     return 0;
 }
 
+static int bnbwd_reduce_launch(const float* dU, int64_t ldu, const float* lr_d, int64_t lr_ld, int lr_k, const float* lr_w,
+                               const uda_src_t* y, const float* mean, const float* invstd, double* sums, void* stream);
+
 extern "C" int uda_bnbwd_reduce(const float* dU, int64_t ldu, const uda_src_t* y, const float* mean, const float* invstd,
                                 double* sums, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
     if (int e = src_check(y, "uda_bnbwd_reduce")) return e;
-    UDA_REQUIRE(y->scale && mean && invstd && sums, "uda_bnbwd_reduce: needs scale/shift/mean/invstd");
     UDA_REQUIRE(dU && uda_aligned16(dU) && ldu % 4 == 0 && ldu >= ((y->C + 3) / 4) * 4, "uda_bnbwd_reduce: bad dU layout");
+    return bnbwd_reduce_launch(dU, ldu, nullptr, 0, 0, nullptr, y, mean, invstd, sums, stream);
+}
+
+/* uda_bnbwd_reduce with the upstream gradient given in low-rank form dU[p, c] = sum_{o < k} d[p, o] * w[o, c], k = 1 or 2: the
+ * input gradient of a 1x1 conv to k outputs (decoder.py:32 305 -> 2, :41 256 -> 1) never has to exist as a [P, C] matrix. */
+extern "C" int uda_bnbwd_reduce_lowrank(const float* d, int64_t ldd, int k, const float* w, const uda_src_t* y, const float* mean,
+                                        const float* invstd, double* sums, void* stream) {
+    if (int e = src_check(y, "uda_bnbwd_reduce_lowrank")) return e;
+    UDA_REQUIRE(d && w && (k == 1 || k == 2) && ldd >= k, "uda_bnbwd_reduce_lowrank: d [P, k], w [k, C], k = 1 or 2");
+    return bnbwd_reduce_launch(nullptr, 0, d, ldd, k, w, y, mean, invstd, sums, stream);
+}
+
+static int bnbwd_reduce_launch(const float* dU, int64_t ldu, const float* lr_d, int64_t lr_ld, int lr_k, const float* lr_w,
+                               const uda_src_t* y, const float* mean, const float* invstd, double* sums, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    UDA_REQUIRE(y->scale && mean && invstd && sums, "uda_bnbwd_reduce: needs scale/shift/mean/invstd");
     const int64_t P = (int64_t)y->N * y->H * y->W;
-    RedArgs a;
+    RedArgs a = {};
     a.x = dU; a.ldx = ldu; a.P = P; a.C = y->C; a.nq = 3; a.y = *y; a.mean = mean; a.invstd = invstd; a.out = sums; a.outC = y->C;
+    a.lr_d = lr_d; a.lr_ld = lr_ld; a.lr_k = lr_k; a.lr_w = lr_w;
     if (red_short(P, y->C))
         hipLaunchKernelGGL((colreduce_kernel<1, 8>), dim3(red_nwg(P, y->C, 8), uda_cdiv(y->C, RED_CBLK_SUM)), dim3(256), 0, st, a);
     else
@@ -510,11 +544,18 @@ extern "C" int uda_bnbwd_finalize(const double* sums, int C, double count, int q
     return 0;
 }
 
+struct LowRank {            // dU[p, c] = sum_{o < k} d[p, o] * w[o, c] (see RedArgs); d = null: dU is a matrix
+    const float* d;
+    int64_t ld;
+    int k;
+    const float* w;
+};
+
 __global__ __launch_bounds__(256) void bnbwd_apply_kernel(const float* __restrict__ dU, int64_t ldu, uda_src_t y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ c1, const float* __restrict__ c2,
                                                           const float* addend, int64_t ld_add, float* out, int64_t ldo,
-                                                          int64_t P) {
+                                                          int64_t P, LowRank lr) {
     const int C = y.C, cblk0 = blockIdx.y * RED_CBLK;
     const int Cb = min(RED_CBLK, C - cblk0), G = (Cb + 3) >> 2, PP = 256 / G;
     const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
@@ -532,14 +573,26 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(const float* __restric
         k1[j] = sc[j] * a2 * is;
         k0[j] = sc[j] * a1 - k1[j] * mu;
     }
+    float lw[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lw[o][j] = (lr.d && o < lr.k && (c0 + j) < C) ? lr.w[(int64_t)o * C + c0 + j] : 0.f;
     const int64_t base = (int64_t)blockIdx.x * (PP * EW_ITER);
 #pragma unroll 4
     for (int it = 0; it < EW_ITER; ++it) {
         const int64_t p = base + (int64_t)it * PP + pl;
         if (p >= P) break;
-        const float4 dv = uda_ld4(dU + p * ldu + c0);
+        float du[4];
+        if (lr.d) {
+            const float d0 = lr.d[p * lr.ld], d1 = lr.k > 1 ? lr.d[p * lr.ld + 1] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) du[j] = d0 * lw[0][j] + d1 * lw[1][j];
+        } else {
+            const float4 dv = uda_ld4(dU + p * ldu + c0);
+            du[0] = dv.x; du[1] = dv.y; du[2] = dv.z; du[3] = dv.w;
+        }
         const float4 yv4 = uda_ld4(y.x + p * y.ldx + c0);
-        const float du[4] = {dv.x, dv.y, dv.z, dv.w};
         const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
         uint32_t mk = 0x01010101u;
         if (y.mask) mk = *reinterpret_cast<const uint32_t*>(y.mask + p * y.ldm + c0);
@@ -567,8 +620,25 @@ extern "C" int uda_bnbwd_apply(const float* dU, int64_t ldu, const uda_src_t* y,
     UDA_REQUIRE(dU && uda_aligned16(dU) && ldu % 4 == 0 && out && uda_aligned16(out) && ldo % 4 == 0, "uda_bnbwd_apply: bad dU/out layout");
     if (addend) UDA_REQUIRE(uda_aligned16(addend) && ld_add % 4 == 0, "uda_bnbwd_apply: bad addend layout");
     const int64_t P = (int64_t)y->N * y->H * y->W;
+    LowRank lr = {nullptr, 0, 0, nullptr};
     hipLaunchKernelGGL(bnbwd_apply_kernel, ew_grid2(P, y->C), dim3(256), 0, (hipStream_t)stream, dU, ldu, *y, mean, invstd,
-                       c1, c2, addend, ld_add, out, ldo, P);
+                       c1, c2, addend, ld_add, out, ldo, P, lr);
     UDA_LAUNCH_CHECK("bnbwd_apply");
+    return 0;
+}
+
+/* uda_bnbwd_apply with the low-rank upstream gradient of uda_bnbwd_reduce_lowrank */
+extern "C" int uda_bnbwd_apply_lowrank(const float* d, int64_t ldd, int k, const float* w, const uda_src_t* y, const float* mean,
+                                       const float* invstd, const float* c1, const float* c2, const float* addend, int64_t ld_add,
+                                       float* out, int64_t ldo, void* stream) {
+    if (int e = src_check(y, "uda_bnbwd_apply_lowrank")) return e;
+    UDA_REQUIRE(y->scale && mean && invstd && c1 && c2, "uda_bnbwd_apply_lowrank: needs scale/shift/mean/invstd/c1/c2");
+    UDA_REQUIRE(d && w && (k == 1 || k == 2) && ldd >= k && out && uda_aligned16(out) && ldo % 4 == 0, "uda_bnbwd_apply_lowrank: bad args");
+    if (addend) UDA_REQUIRE(uda_aligned16(addend) && ld_add % 4 == 0, "uda_bnbwd_apply_lowrank: bad addend layout");
+    const int64_t P = (int64_t)y->N * y->H * y->W;
+    LowRank lr = {d, ldd, k, w};
+    hipLaunchKernelGGL(bnbwd_apply_kernel, ew_grid2(P, y->C), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, (int64_t)0, *y,
+                       mean, invstd, c1, c2, addend, ld_add, out, ldo, P, lr);
+    UDA_LAUNCH_CHECK("bnbwd_apply_lowrank");
     return 0;
 }

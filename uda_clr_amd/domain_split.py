@@ -133,11 +133,17 @@ class DomainSplit:
             self.K.dwconv_wgrad(src.half(h), _rows(dy, src.N, n0, n1), stride, dil, border_mode, dst)
         dw.add_(d1)
 
-    def bnbwd_reduce(self, dU, y: Act, sums):
+    @staticmethod
+    def _lr(lowrank, N, n0, n1):
+        return None if lowrank is None else (_rows(lowrank[0], N, n0, n1), lowrank[1])
+
+    def bnbwd_reduce(self, dU, y: Act, sums, lowrank=None):
+        kw = {} if lowrank is None else {"lowrank": lowrank}
         if not y.split:
-            return self.K.bnbwd_reduce(dU, y, sums)
+            return self.K.bnbwd_reduce(dU, y, sums, **kw)
         for h, n0, n1 in self._halves(y.N):
-            self.K.bnbwd_reduce(_rows(dU, y.N, n0, n1), y.half(h), sums[h])
+            kh = {} if lowrank is None else {"lowrank": self._lr(lowrank, y.N, n0, n1)}
+            self.K.bnbwd_reduce(None if dU is None else _rows(dU, y.N, n0, n1), y.half(h), sums[h], **kh)
 
     def bnbwd_finalize(self, sums, y: Act, c1, c2, dgamma, dbeta, q1_total=None):
         if not y.split:
@@ -145,9 +151,11 @@ class DomainSplit:
         for h in (0, 1):
             self.K.bnbwd_finalize(sums[h], y.half(h), c1[h], c2[h], dgamma[h], dbeta[h])
 
-    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None):
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None, lowrank=None):
+        kw = {} if lowrank is None else {"lowrank": lowrank}
         if not y.split:
-            return self.K.bnbwd_apply(dU, y, c1, c2, out, addend)
+            return self.K.bnbwd_apply(dU, y, c1, c2, out, addend, **kw)
         for h, n0, n1 in self._halves(y.N):
-            self.K.bnbwd_apply(_rows(dU, y.N, n0, n1), y.half(h), c1[h], c2[h], _rows(out, y.N, n0, n1),
-                               None if addend is None else _rows(addend, y.N, n0, n1))
+            kh = {} if lowrank is None else {"lowrank": self._lr(lowrank, y.N, n0, n1)}
+            self.K.bnbwd_apply(None if dU is None else _rows(dU, y.N, n0, n1), y.half(h), c1[h], c2[h], _rows(out, y.N, n0, n1),
+                               None if addend is None else _rows(addend, y.N, n0, n1), **kh)

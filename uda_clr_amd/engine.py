@@ -788,10 +788,13 @@ class GeneratorEngine:
         return out
 
     # ------------------------------------------------------------------ backward pieces
-    def _bn_backward(self, ctx, G, y: Act, dU, out=None, addend=None, keys=None, q1_total=None):
+    def _bn_backward(self, ctx, G, y: Act, dU, out=None, addend=None, keys=None, q1_total=None, lowrank=None):
         """dU: gradient w.r.t. the activated values of ``y``.  Writes the gradient w.r.t. the raw
-        tensor y.x into ``out`` (default: in place over dU) and the BN parameter gradients into G."""
+        tensor y.x into ``out`` (default: in place over dU) and the BN parameter gradients into G.
+        ``lowrank`` = (d [P, k], w [k, C]) instead of dU: the gradient is the outer product d @ w (the input gradient of a 1x1 conv
+        to one or two outputs) and is formed inside the two passes, never written (``out`` is then required)."""
         K = self.K
+        lr = {} if lowrank is None else {"lowrank": lowrank}
         if y.bn is None:
             raise RuntimeError("this activation's BatchNorm kept no backward record (forward ran without gradient bookkeeping)")
         C = y.C
@@ -799,14 +802,14 @@ class GeneratorEngine:
             # TransNorm: z = (xhat*gamma + beta) * gain per domain half, gain detached (batchnorm.py:495).  The per-half
             # kernels see gamma*gain as the scale, so dx is already right; the shared gamma / beta collect gain * (per-half sums)
             sums = ctx.arena.take(3, C, 2)
-            cg = self._empty(dU, 4, 2, C)
+            cg = self._empty(y.x, 4, 2, C)
         else:
             sums = ctx.arena.take(3, C)
-            cg = self._empty(dU, 4, C)
-        K.bnbwd_reduce(dU, y, sums)
+            cg = self._empty(y.x, 4, C)
+        K.bnbwd_reduce(dU, y, sums, **lr)
         K.bnbwd_finalize(sums, y, cg[0], cg[1], cg[2], cg[3], **({} if q1_total is None else {"q1_total": q1_total}))
         out = dU if out is None else out
-        K.bnbwd_apply(dU, y, cg[0], cg[1], out, addend)
+        K.bnbwd_apply(dU, y, cg[0], cg[1], out, addend, **lr)
         if y.split:
             dg, db = (cg[2] * y.bn.gain).sum(0), (cg[3] * y.bn.gain).sum(0)
         elif y.bn.gain is not None and y.bn.frozen:      # frozen TransNorm: one coefficient set, the constant gain on the affine gradients
@@ -867,21 +870,22 @@ class GeneratorEngine:
         sa = D["sa"]
         self._wgrad(ctx, G, "decoder.last_conv.3.weight", sa, d_x1b, 1, 1)
         self._bias_grad(G, "decoder.last_conv.3.bias", d_x1b)
-        dU = self._buf(x, P4, 305)
-        self._dgrad(ctx, "decoder.last_conv.3.weight", d_x1b, N, H4, W4, 1, 1, dU)
-        self._bn_backward(ctx, G, sa, dU, out=d_xf[:, :305], addend=d_xf[:, :305])
+        # the input gradient of the 305 -> 2 head is the outer product d_x1b @ W: formed inside the BN-backward passes
+        w_head = ctx.params["decoder.last_conv.3.weight"].reshape(2, 305).contiguous()
+        self._bn_backward(ctx, G, sa, None, out=d_xf[:, :305], addend=d_xf[:, :305],
+                          lowrank=(d_x1b, w_head))
         # ---- boundary head (decoder.py:33-41)
         b1, b2 = D["b1"], D["b2"]
         d_x2b = d_xf[:, 304:305]
         self._wgrad(ctx, G, "decoder.last_conv_boundary.8.weight", b2, d_x2b, 1, 1)
         self._bias_grad(G, "decoder.last_conv_boundary.8.bias", d_x2b)
-        dU2 = self._empty(x, P4, 256)
-        self._dgrad(ctx, "decoder.last_conv_boundary.8.weight", d_x2b, N, H4, W4, 1, 1, dU2)
-        dy2 = self._bn_backward(ctx, G, b2, dU2)
+        dy2 = self._empty(x, P4, 256)
+        w_bnd = ctx.params["decoder.last_conv_boundary.8.weight"].reshape(1, 256).contiguous()
+        self._bn_backward(ctx, G, b2, None, out=dy2, lowrank=(d_x2b, w_bnd))       # 256 -> 1 head: rank one
         self._wgrad(ctx, G, "decoder.last_conv_boundary.4.weight", b1, dy2, 3, 1)
         dU1 = self._empty(x, P4, 256)
         self._dgrad(ctx, "decoder.last_conv_boundary.4.weight", dy2, N, H4, W4, 3, 1, dU1)
-        del dU2, dy2
+        del dy2
         dy1 = self._bn_backward(ctx, G, b1, dU1)
         # conv0, split as in _conv0: low-level part on the high-resolution kernels, upsampled part through the adjoint
         # interpolation (dG) and low-resolution GEMMs

@@ -91,6 +91,8 @@ SYMBOLS = {
     "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P]),
     "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "uda_bnbwd_apply": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
+    "uda_bnbwd_reduce_lowrank": (_I, [_P, _L, _I, _P, C.POINTER(UdaSrc), _P, _P, _P, _P]),
+    "uda_bnbwd_apply_lowrank": (_I, [_P, _L, _I, _P, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "uda_upsample_fwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
     "uda_upsample_bwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P]),
     "uda_head_upsample_fwd": (_I, [_P, _L, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -669,10 +671,24 @@ class HipKernels:
         self.colstats(x, st)
         out.copy_(st.sum(0)[0])
 
-    def bnbwd_reduce(self, dU, y: Act, sums):
+    @staticmethod
+    def _lowrank(lowrank, y):
+        """(d [P, k] rows, w [k, C] contiguous) of dU = d @ w, k = 1 or 2"""
+        d, w = lowrank
+        k = d.shape[1]
+        assert k in (1, 2) and d.shape[0] == y.P and tuple(w.shape) == (k, y.C) and w.is_contiguous() and d.stride(1) == 1
+        assert d.dtype == w.dtype == torch.float32
+        return d.data_ptr(), d.stride(0), k, w.data_ptr()
+
+    def bnbwd_reduce(self, dU, y: Act, sums, lowrank=None):
         s = self._src(y)
-        assert dU.shape == y.x.shape and sums.dtype == torch.float64 and tuple(sums.shape) == (STAT_SLOTS, 3, y.C)
-        assert sums.is_contiguous()
+        assert sums.dtype == torch.float64 and tuple(sums.shape) == (STAT_SLOTS, 3, y.C) and sums.is_contiguous()
+        if lowrank is not None:
+            dp, ldd, k, wp = self._lowrank(lowrank, y)
+            self._ck(self.lib.uda_bnbwd_reduce_lowrank(dp, ldd, k, wp, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
+                                                       sums.data_ptr(), self._stream()))
+            return
+        assert dU.shape == y.x.shape
         d, ldu = _mat(dU, "dU")
         self._ck(self.lib.uda_bnbwd_reduce(d, ldu, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
                                            sums.data_ptr(), self._stream()))
@@ -685,12 +701,18 @@ class HipKernels:
                                              c1.data_ptr(), c2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                              self._stream()))
 
-    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None):
+    def bnbwd_apply(self, dU, y: Act, c1, c2, out, addend=None, lowrank=None):
         s = self._src(y)
-        assert dU.shape == y.x.shape == out.shape
-        d, ldu = _mat(dU, "dU")
+        assert y.x.shape == out.shape
         o, ldo = _mat(out, "out")
         ad, lda = (None, 0) if addend is None else _mat(addend, "addend")
+        if lowrank is not None:
+            dp, ldd, k, wp = self._lowrank(lowrank, y)
+            self._ck(self.lib.uda_bnbwd_apply_lowrank(dp, ldd, k, wp, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
+                                                      c1.data_ptr(), c2.data_ptr(), ad, lda, o, ldo, self._stream()))
+            return
+        assert dU.shape == y.x.shape
+        d, ldu = _mat(dU, "dU")
         self._ck(self.lib.uda_bnbwd_apply(d, ldu, C.byref(s), y.bn.mean.data_ptr(), y.bn.invstd.data_ptr(),
                                           c1.data_ptr(), c2.data_ptr(), ad, lda, o, ldo, self._stream()))
 

@@ -479,8 +479,6 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
 }
 
 // Sum of the tail launch's partial tiles into y (+ bias, + addend), fixed order: bitwise reproducible.
-extern "C" int uda_colstats(const float* x, int64_t ldx, int64_t P, int C, int nq, double* out, void* stream);
-
 struct X3TailArgs {
     const float* partial;     // [ntail * ksplit][BM][BN]
     int ksplit, tile_off, ntail, nNt, BM, BN, Cout;
@@ -524,25 +522,12 @@ struct X3Tail {
     int ksplit;
 };
 
-// has_stats: the conv accumulates BN statistics in its epilogue.  The partial tiles of a split cannot; a launch whose tiles ALL fit
-// one partly filled round (the ASPP's atrous convs: 256 tiles of 128 x 128 on 16384 pixels, K = 2880) is still split - every tile
-// over 2-8 workgroups, two of them resident per CU - and its statistics are taken from y by one uda_colstats pass afterwards;
-// launches with full rounds keep their epilogue statistics and are not split.
-static X3Tail x3_tail_plan(int64_t P, int Cout, int nchunks, int BM, int BN, bool allow, bool has_stats = false) {
+static X3Tail x3_tail_plan(int64_t P, int Cout, int nchunks, int BM, int BN, bool allow) {
     X3Tail t;
     t.tiles = uda_cdiv(P, BM) * uda_cdiv(Cout, BN);
     t.full = (t.tiles / 256) * 256;
     t.tail = t.tiles - t.full;
     t.ksplit = 1;
-    static const int all_tail = getenv("UDA_X3_SPLIT_UNDERFILLED") ? atoi(getenv("UDA_X3_SPLIT_UNDERFILLED")) : 1;
-    if (allow && all_tail && t.full == 0 && nchunks >= 96 && BM * BN <= 128 * 128) {     // (64 VGPRs: two 128 x 128 workgroups fit a CU)
-        // an under-filled single round: split EVERY tile so that ~2 workgroups per CU are resident (the 128-row tiles leave room)
-        int s = (int)(512 / t.tiles);
-        if (s > 8) s = 8;
-        if (s > nchunks / 8) s = nchunks / 8;
-        if (s >= 2) { t.ksplit = s; return t; }
-    }
-    if (has_stats) return t;
     // only where it clearly pays: a long K (the fp32 partial tiles are extra traffic - one write and one read per split - and on the
     // short-K layers the split bought 2-3 %) and at least three splits (measured: discriminator L3 / L4 forward 10 % / 16 %)
     static const int mode = getenv("UDA_X3_TAIL_MODE") ? atoi(getenv("UDA_X3_TAIL_MODE")) : 1;      // experiment: 2 = every tail <= 128 tiles
@@ -580,9 +565,8 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, 
     const int dbg = 0;
 #endif
     k.debug = dbg;
-    X3Tail t = x3_tail_plan(P, k.Cout, k.nchunks, BM, BN, ws != nullptr, k.stats != nullptr);
+    X3Tail t = x3_tail_plan(P, k.Cout, k.nchunks, BM, BN, k.stats == nullptr && ws != nullptr);
     if (x3_tail_bytes(t, BM, BN) > ws_bytes) t.ksplit = 1;
-    UDA_REQUIRE(!(k.stats && t.ksplit > 1 && t.full > 0), "igemm_conv_x3: a split tail cannot accumulate statistics");
     k.tile_off = 0; k.ksplit = 1; k.partial = nullptr;
     k.ntiles_main = (int)(t.ksplit > 1 ? t.full : t.tiles);
     if (k.ntiles_main > 0) {
@@ -607,9 +591,6 @@ static int launch_x3(X3KArgs& k, int64_t P, hipStream_t st, void* ws = nullptr, 
         const int64_t work = (int64_t)t.tail * BM * (BN / 4);
         hipLaunchKernelGGL(x3_tail_reduce_kernel, dim3((int)uda_cdiv(work, 256)), dim3(256), 0, st, r);
         UDA_LAUNCH_CHECK("x3_tail_reduce");
-        if (k.stats) {       // every tile was split (x3_tail_plan): the statistics of y in one pass over it
-            if (int e = uda_colstats(k.y, k.ldy, P, k.Cout, 2, k.stats, st)) return e;
-        }
     }
     return 0;
 }
@@ -697,7 +678,7 @@ extern "C" int uda_x3_pack_s2d_bwd(const float* dz, int64_t ld_z, int Hz, int Wz
 // filled last round both count; with a workspace and no statistics epilogue that last round is split over K (x3_tail_plan) and
 // costs 1 / ksplit of a round plus the reduce.  Efficiencies fitted to the discriminator layers (tests/bench_x3.py with
 // UDA_X3_TILE forcing a tile; the tiles stage 32 / 48 / 48 / 64 B per MFMA clock and CU, two 128 x 128 workgroups can share a CU).
-static int x3_pick_tile(int64_t P, int Cout, int nchunks, bool allow_tail, bool has_stats = false) {
+static int x3_pick_tile(int64_t P, int Cout, int nchunks, bool allow_tail) {
     static const int force = getenv("UDA_X3_TILE") ? atoi(getenv("UDA_X3_TILE")) : -1;
     if (force >= 0 && force < 4) return force;
     const int bm[4] = {256, 128, 256, 128}, bn[4] = {256, 256, 128, 128};
@@ -705,7 +686,7 @@ static int x3_pick_tile(int64_t P, int Cout, int nchunks, bool allow_tail, bool 
     int best = 0;
     double bestc = 1e300;
     for (int t = 0; t < 4; ++t) {
-        const X3Tail tp = x3_tail_plan(P, Cout, nchunks, bm[t], bn[t], allow_tail, has_stats);
+        const X3Tail tp = x3_tail_plan(P, Cout, nchunks, bm[t], bn[t], allow_tail);
         double rounds = (double)(tp.full / 256);
         if (tp.tail > 0) rounds += tp.ksplit > 1 ? 1.0 / tp.ksplit + 0.12 : 1.0;
         const double c = rounds * bm[t] * bn[t] / eff[t];
@@ -719,11 +700,10 @@ static const int X3_TILE_BM[4] = {256, 128, 256, 128}, X3_TILE_BN[4] = {256, 256
 // workspace the tail split of this conv wants (0: none)
 uint64_t conv_x3_workspace_bytes(const ConvKArgs& k, int64_t P) {
     static const bool off = getenv("UDA_X3_NO_TAIL") != nullptr;
-    if (off || (k.ksize >= 2 && k.Cout <= 64)) return 0;
+    if (off || k.stats || (k.ksize >= 2 && k.Cout <= 64)) return 0;
     const int nch = uda_cdiv(k.Ktot, X3_BK);
-    const bool hs = k.stats != nullptr;
-    const int t = x3_pick_tile(P, k.Cout, nch, true, hs);
-    return x3_tail_bytes(x3_tail_plan(P, k.Cout, nch, X3_TILE_BM[t], X3_TILE_BN[t], true, hs), X3_TILE_BM[t], X3_TILE_BN[t]);
+    const int t = x3_pick_tile(P, k.Cout, nch, true);
+    return x3_tail_bytes(x3_tail_plan(P, k.Cout, nch, X3_TILE_BM[t], X3_TILE_BN[t], true), X3_TILE_BM[t], X3_TILE_BN[t]);
 }
 
 int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w, hipStream_t st, void* ws, uint64_t ws_bytes) {
@@ -742,7 +722,7 @@ int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w
     const uint64_t want = conv_x3_workspace_bytes(k, P);
     const bool tail_ok = want > 0 && ws != nullptr && ws_bytes >= want && uda_aligned16(ws);
     if (!tail_ok) { ws = nullptr; ws_bytes = 0; }
-    const int best = x3_pick_tile(P, k.Cout, nch, tail_ok, k.stats != nullptr);
+    const int best = x3_pick_tile(P, k.Cout, nch, tail_ok);
     if (k.ksize >= 2) {
         switch (best) {
             case 0: return launch_x3<3, 4, 256>(x, P, st, ws, ws_bytes);

@@ -257,6 +257,17 @@ int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w, int C, fl
  * stats = double[UDA_STAT_SLOTS][2][stat_C]; needs 256 % (C / 4) == 0 */
 int uda_upsample_fwd_stats(const float* x, int64_t ldx, int N, int h, int w, int C, float* out, int64_t ldo, int H, int W,
                            double* stats, int stat_C, void* stream);
+/* (out = NULL: statistics only, the upsampled tensor is not written.)
+ * uda_mc_seg_head: the segmentation head of a no-grad stochastic pass (Trainer_prototype_full.py:358-368; decoder.py:23-32,51-53):
+ *     x1b[p, o] = bias[o] + sum_c w[o][c] * mask[p, c] * mask_scale * act(scale[c] * xf[p, c] + shift[c]),  o = 0, 1,
+ *     xf[p, :] = cat(bilinear_up(feature)[p, 0:Cf], low[p mod P_low, 0:Cl], boundary[p])
+ * WITHOUT the [P, Cf + Cl + 1] x_feature matrix: the upsampled channels are interpolated on the fly from feature [N*h*w, Cf], the
+ * low-level channels come from the un-repeated rows low [P_low, Cl] (x.repeat(2) shares them), the boundary logit from its own
+ * column.  weight: two rows of ldw floats (uda_relayout_ohwi of decoder.last_conv.3.weight); mask: uint8 [P][ldm] or NULL. */
+int uda_mc_seg_head(const float* feature, int64_t ld_feat, int N, int h, int w, int Cf, const float* low, int64_t ld_low,
+                    int Cl, int64_t P_low, const float* boundary, int64_t ld_bnd, int H, int W, const float* scale,
+                    const float* shift, int act, const uint8_t* mask, int64_t ldm, float mask_scale, const float* weight,
+                    int64_t ldw, const float* bias, float* out, int64_t ldo, void* stream);
 int uda_upsample_bwd(const float* dout, int64_t ldo, int N, int H, int W, int C, float* dx,
                      int64_t ldx, int h, int w, void* stream);
 /* NHWC [N*h*w, C<=4] -> contiguous NCHW [N][C][H][W] and its adjoint */

@@ -359,6 +359,37 @@ def case_bnbwd_lowrank(P, C, k, mask, seed=9):
     return run
 
 
+def case_mc_seg_head(N, h, w, H, W, Cf, Cl, reps, mask, seed=10):
+    """uda_mc_seg_head (the 305 -> 2 head of a no-grad stochastic pass on the virtual x_feature = cat(up(feature), low rows shared by
+    the repeated batch, boundary)) and the store-less statistics pass uda_upsample_fwd_stats(out = NULL), against the torch statement
+    that materialises the matrix."""
+    def run(dev):
+        g = gen(seed)
+        K = hip()
+        P, Cc = N * H * W, Cf + Cl + 1
+        feat = padded(N * h * w, Cf, g)
+        low = padded(P // reps, Cl, g)
+        bnd = padded(P, 1, g)
+        sc, sh = 0.5 + torch.rand(Cc, generator=g), 0.3 * torch.randn(Cc, generator=g)
+        mk = None
+        if mask:
+            mbuf = torch.randint(0, 256, (P, round4(Cc)), generator=g, dtype=torch.uint8)     # padding bytes arbitrary
+            mbuf[:, :Cc] = (torch.rand(P, Cc, generator=g) > 0.1).to(torch.uint8)
+            mk = mbuf[:, :Cc]
+        w4 = torch.randn(2, Cc, 1, 1, generator=g) / Cc ** 0.5
+        bias = torch.randn(2, generator=g)
+        o_r, o_h = padded(P, 2, g), to_dev(padded(P, 2, g), dev)
+        SPEC.mc_seg_head(feat, N, h, w, low, bnd, H, W, sc, sh, ACT_RELU, mk, 1.0 / 0.9, SPEC.relayout_ohwi(w4), bias, o_r)
+        K.mc_seg_head(to_dev(feat, dev), N, h, w, to_dev(low, dev), to_dev(bnd, dev), H, W, sc.to(dev), sh.to(dev), ACT_RELU,
+                      None if mk is None else to_dev(mbuf, dev)[:, :Cc], 1.0 / 0.9, K.relayout_ohwi(w4.to(dev)), bias.to(dev), o_h)
+        st_r = torch.zeros(16, 2, Cc, dtype=torch.float64)
+        st_h = torch.zeros(16, 2, Cc, dtype=torch.float64, device=dev)
+        SPEC.upsample_stats(feat, N, h, w, H, W, st_r)
+        K.upsample_stats(to_dev(feat, dev), N, h, w, H, W, st_h)
+        return max(rel(o_h, o_r), rel(st_h.sum(0), st_r.sum(0))), 2e-5
+    return run
+
+
 def case_upsample_stats(N, h, w, H, W, C, Cs, seed=8):
     """uda_upsample_fwd_stats: the upsampled tensor AND its per-channel (sum, sum of squares) in channels [0, C) of a wider
     accumulator; uda_colstats_window: the remaining channels of the wide buffer (a strided column window) into the same accumulator
@@ -534,6 +565,8 @@ CASES = [
     ("upsample 4x4->16x16 C=256", case_resample(2, 4, 4, 16, 16, 256)),
     ("upsample 8x6->32x24 C=64", case_resample(1, 8, 6, 32, 24, 64)),
     ("upsample + stats 8x8->32x32 C=256 into 305 (+ 49-channel window)", case_upsample_stats(2, 8, 8, 32, 32, 256, 305)),
+    ("mc seg head 4 x (8x8 -> 32x32) 256 + 48 + 1, batch repeated twice, mask", case_mc_seg_head(4, 8, 8, 32, 32, 256, 48, 2, True)),
+    ("mc seg head 3 x (5x7 -> 20x28) 64 + 8 + 1, no repeat, no mask", case_mc_seg_head(3, 5, 7, 20, 28, 64, 8, 1, False)),
     ("bn backward, low-rank dU: C=305 k=2 mask (seg head)", case_bnbwd_lowrank(3000, 305, 2, True)),
     ("bn backward, low-rank dU: C=256 k=1 mask (boundary head)", case_bnbwd_lowrank(2500, 256, 1, True)),
     ("bn backward, low-rank dU: C=40 k=2 raw", case_bnbwd_lowrank(777, 40, 2, False)),

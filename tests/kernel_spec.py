@@ -422,6 +422,22 @@ class SpecKernels:
         if stats is not None:
             self.colstats_window(out, stats, 0)
 
+    def upsample_stats(self, x, N, h, w, H, W, stats):
+        tmp = torch.empty(N * H * W, x.shape[1], dtype=x.dtype, device=x.device)
+        self.upsample_fwd(x, N, h, w, tmp, H, W, stats=stats)
+
+    def mc_seg_head(self, feature, N, h, w, low, bnd, H, W, scale, shift, act, mask, mask_scale, wgt, bias, out):
+        """x1b = W . (mask * ms * act(scale * xf + shift)) + bias on xf = cat(up(feature), low repeated over the batch, boundary)"""
+        P, Cf, Cl = N * H * W, feature.shape[1], low.shape[1]
+        Cc = Cf + Cl + 1
+        xf = torch.empty(P, Cc, dtype=feature.dtype, device=feature.device)
+        self.upsample_fwd(feature, N, h, w, xf[:, :Cf], H, W)
+        xf[:, Cf:Cf + Cl] = low.repeat(P // low.shape[0], 1)
+        xf[:, Cf + Cl:] = bnd
+        u = transform(Act(xf, N, H, W, scale, shift, act, mask, mask_scale))
+        wm = wgt.reshape(2, -1)[:, :Cc]
+        out.copy_(u @ wm.t() + bias)
+
     def upsample_bwd(self, dout, N, H, W, dx, h, w):
         mh, mw = _bilinear_matrix(h, H, dout.device, dout.dtype), _bilinear_matrix(w, W, dout.device, dout.dtype)
         t = dout.reshape(N, H, W, -1)

@@ -11,7 +11,7 @@
 // STATS: per-channel (sum, sum of squares) of the OUTPUT accumulated on the way (a thread's channel group is fixed over its
 // grid-stride iterations because 256 % (C / 4) == 0; the host checks it): per-thread fp32 partial sums, the 256 / G threads of a
 // channel group combined through LDS, then fp64 atomics into one of the UDA_STAT_SLOTS replicas of double[2][stat_C].
-template <bool STATS>
+template <bool STATS, bool STORE = true>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int64_t ldx, int N, int h, int w,
                                                            int C, float* __restrict__ out, int64_t ldo, int H, int W,
                                                            float sh, float sw, double* __restrict__ stats, int stat_C) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         r.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
         r.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
         r.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
-        uda_st4(out + p * ldo + cg * 4, r);
+        if (STORE) uda_st4(out + p * ldo + cg * 4, r);
         if (STATS) {
             s1[0] += r.x; s1[1] += r.y; s1[2] += r.z; s1[3] += r.w;
             s2[0] += r.x * r.x; s2[1] += r.y * r.y; s2[2] += r.z * r.z; s2[3] += r.w * r.w;
@@ -106,16 +106,138 @@ extern "C" int uda_upsample_fwd(const float* x, int64_t ldx, int N, int h, int w
  * the 256 upsampled channels' statistics come from the pass that writes them).  Needs 256 % (C / 4) == 0. */
 extern "C" int uda_upsample_fwd_stats(const float* x, int64_t ldx, int N, int h, int w, int C, float* out, int64_t ldo, int H,
                                       int W, double* stats, int stat_C, void* stream) {
-    UDA_REQUIRE(x && out && uda_aligned16(x) && uda_aligned16(out) && ldx % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && C > 0 &&
-                    ldx >= C && ldo >= C, "uda_upsample_fwd_stats: C and lds must be multiples of 4, pointers 16-byte aligned");
+    UDA_REQUIRE(x && uda_aligned16(x) && ldx % 4 == 0 && C % 4 == 0 && C > 0 && ldx >= C &&
+                    (!out || (uda_aligned16(out) && ldo % 4 == 0 && ldo >= C)),
+                "uda_upsample_fwd_stats: C and lds must be multiples of 4, pointers 16-byte aligned");
     UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "uda_upsample_fwd_stats: bad geometry");
     UDA_REQUIRE(stats && stat_C >= C && 256 % (C / 4) == 0, "uda_upsample_fwd_stats: needs an accumulator and 256 %% (C / 4) == 0");
     const int64_t total = (int64_t)N * H * W * (C / 4);
     int grid = uda_cdiv(total, 256);
     if (grid > 4096) grid = 4096;                 // (fewer, longer threads: one LDS reduction + 2C fp64 atomics per workgroup)
-    hipLaunchKernelGGL(upsample_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo, H, W,
-                       bil_scale(h, H), bil_scale(w, W), stats, stat_C);
+    if (out)
+        hipLaunchKernelGGL((upsample_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo,
+                           H, W, bil_scale(h, H), bil_scale(w, W), stats, stat_C);
+    else        // out = NULL: the statistics of the upsampled tensor without writing it (uda_mc_seg_head re-derives its values)
+        hipLaunchKernelGGL((upsample_fwd_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, h, w, C, out, ldo,
+                           H, W, bil_scale(h, H), bil_scale(w, W), stats, stat_C);
     UDA_LAUNCH_CHECK("upsample_fwd_stats");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The segmentation head of a NO-GRAD stochastic pass (Trainer_prototype_full.py:358-368 -> decoder.py:23-32,51-53 + :53's cat):
+//     x1b[p, o] = bias[o] + sum_c w[o, c] * mask[p, c] * ms * act(scale[c] * xf[p, c] + shift[c]),
+//     xf[p, :] = cat(up(feature)[p, 0:Cf], low[p mod P_low, 0:Cl], boundary[p])
+// with the 305-channel x_feature matrix xf never written: the upsampled channels are interpolated on the fly from the small
+// feature map (4 cached 16-byte reads per 4 channels instead of a 1 KB row per pixel), the low-level channels come from the
+// un-repeated [P_low, Cl] rows (the repeated batch shares them), the boundary logit from its own column.  16 lanes per pixel,
+// coefficients and weights in LDS - the structure of conv_heads_kernel (igemm_conv.hip), same summation order.
+struct McHeadArgs {
+    const float* feat; int64_t ld_feat; int N, h, w, Cf;
+    const float* low; int64_t ld_low; int Cl; int64_t P_low;
+    const float* bnd; int64_t ld_bnd;
+    int H, W;
+    const float* scale; const float* shift;
+    int act;
+    const uint8_t* mask; int64_t ldm; float mask_scale;
+    const float* wgt; int64_t ldw;
+    const float* bias;
+    float* out; int64_t ldo;
+    float sh, sw;
+};
+
+__global__ __launch_bounds__(256) void mc_seg_head_kernel(McHeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];       // [4][Kc]: scale, shift, w[0], w[1]
+    const int C = a.Cf + a.Cl + 1, Kc = ((C + 3) >> 2) << 2;
+    for (int e = threadIdx.x; e < Kc; e += 256) {
+        const bool in = e < C;
+        hsm[e] = (in && a.scale) ? a.scale[e] : 1.f;
+        hsm[Kc + e] = (in && a.shift) ? a.shift[e] : 0.f;
+        hsm[2 * Kc + e] = in ? a.wgt[e] : 0.f;
+        hsm[3 * Kc + e] = in ? a.wgt[a.ldw + e] : 0.f;
+    }
+    __syncthreads();
+    const int l16 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int64_t P = (int64_t)a.N * a.H * a.W;
+    const float alo = a.act == ACT_NONE ? -INFINITY : 0.f, ahi = a.act == ACT_RELU6 ? 6.f : INFINITY;
+    const float ms = a.mask_scale;
+    const int G = Kc >> 2;
+    for (int it = 0; it < 8; ++it) {
+        const int64_t p = (int64_t)blockIdx.x * 128 + it * 16 + pl;
+        float acc0 = 0.f, acc1 = 0.f;
+        if (p < P) {
+            const int ow = (int)(p % a.W), oh = (int)((p / a.W) % a.H);
+            const int64_t n = p / ((int64_t)a.W * a.H);
+            int h0, h1, w0, w1;
+            float lh0, lh1, lw0, lw1;
+            bil_src(oh, a.sh, a.h, h0, h1, lh0, lh1);
+            bil_src(ow, a.sw, a.w, w0, w1, lw0, lw1);
+            const float* fb = a.feat + n * a.h * a.w * a.ld_feat;
+            const float* f00 = fb + ((int64_t)h0 * a.w + w0) * a.ld_feat, *f01 = fb + ((int64_t)h0 * a.w + w1) * a.ld_feat;
+            const float* f10 = fb + ((int64_t)h1 * a.w + w0) * a.ld_feat, *f11 = fb + ((int64_t)h1 * a.w + w1) * a.ld_feat;
+            const float* lr = a.low + (p % a.P_low) * a.ld_low;
+            for (int g = l16; g < G; g += 16) {
+                const int c = g * 4;
+                float4 xv;
+                if (c < a.Cf) {
+                    const float4 a00 = uda_ld4(f00 + c), a01 = uda_ld4(f01 + c), a10 = uda_ld4(f10 + c), a11 = uda_ld4(f11 + c);
+                    xv.x = lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
+                    xv.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
+                    xv.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
+                    xv.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
+                } else if (c < a.Cf + a.Cl) {
+                    xv = uda_ld4(lr + (c - a.Cf));
+                } else {
+                    xv = make_float4(a.bnd[p * a.ld_bnd], 0.f, 0.f, 0.f);
+                }
+                const float4 sc = uda_ld4(&hsm[c]), shv = uda_ld4(&hsm[Kc + c]);
+                float u[4] = {__builtin_amdgcn_fmed3f(xv.x * sc.x + shv.x, alo, ahi), __builtin_amdgcn_fmed3f(xv.y * sc.y + shv.y, alo, ahi),
+                              __builtin_amdgcn_fmed3f(xv.z * sc.z + shv.z, alo, ahi), __builtin_amdgcn_fmed3f(xv.w * sc.w + shv.w, alo, ahi)};
+                if (a.mask) {
+                    uint32_t mk = *reinterpret_cast<const uint32_t*>(a.mask + p * a.ldm + c);
+                    if (c + 4 > C) mk &= 0xffffffffu >> (8 * (c + 4 - C));
+                    u[0] *= (float)(mk & 0xffu) * ms; u[1] *= (float)((mk >> 8) & 0xffu) * ms;
+                    u[2] *= (float)((mk >> 16) & 0xffu) * ms; u[3] *= (float)(mk >> 24) * ms;
+                }
+                const float4 w0v = uda_ld4(&hsm[2 * Kc + c]), w1v = uda_ld4(&hsm[3 * Kc + c]);      // zero beyond C
+                acc0 += u[0] * w0v.x + u[1] * w0v.y + u[2] * w0v.z + u[3] * w0v.w;
+                acc1 += u[0] * w1v.x + u[1] * w1v.y + u[2] * w1v.z + u[3] * w1v.w;
+            }
+        }
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+            acc0 += __shfl_xor(acc0, d);
+            acc1 += __shfl_xor(acc1, d);
+        }
+        if (l16 == 0 && p < P) {
+            a.out[p * a.ldo] = acc0 + (a.bias ? a.bias[0] : 0.f);
+            a.out[p * a.ldo + 1] = acc1 + (a.bias ? a.bias[1] : 0.f);
+        }
+    }
+}
+
+extern "C" int uda_mc_seg_head(const float* feature, int64_t ld_feat, int N, int h, int w, int Cf, const float* low, int64_t ld_low,
+                               int Cl, int64_t P_low, const float* boundary, int64_t ld_bnd, int H, int W, const float* scale,
+                               const float* shift, int act, const uint8_t* mask, int64_t ldm, float mask_scale, const float* weight,
+                               int64_t ldw, const float* bias, float* out, int64_t ldo, void* stream) {
+    UDA_REQUIRE(feature && low && boundary && weight && out && uda_aligned16(feature) && uda_aligned16(low) && ld_feat % 4 == 0 &&
+                    ld_low % 4 == 0 && Cf > 0 && Cf % 4 == 0 && Cl > 0 && Cl % 4 == 0 && ld_feat >= Cf && ld_low >= Cl && ld_bnd >= 1 &&
+                    ldo >= 2 && ldw >= Cf + Cl + 1, "uda_mc_seg_head: bad operands (channel counts multiples of 4, 16-byte aligned rows)");
+    UDA_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && P_low > 0 && ((int64_t)N * H * W) % P_low == 0,
+                "uda_mc_seg_head: bad geometry (the low-level rows must tile the pixels)");
+    UDA_REQUIRE(!mask || (((reinterpret_cast<uintptr_t>(mask)) & 3u) == 0 && ldm % 4 == 0 && ldm >= ((Cf + Cl + 1 + 3) / 4) * 4),
+                "uda_mc_seg_head: mask rows must be 4-byte aligned and hold round4(C) bytes");
+    McHeadArgs a;
+    a.feat = feature; a.ld_feat = ld_feat; a.N = N; a.h = h; a.w = w; a.Cf = Cf;
+    a.low = low; a.ld_low = ld_low; a.Cl = Cl; a.P_low = P_low;
+    a.bnd = boundary; a.ld_bnd = ld_bnd; a.H = H; a.W = W;
+    a.scale = scale; a.shift = shift; a.act = act; a.mask = mask; a.ldm = ldm; a.mask_scale = mask_scale;
+    a.wgt = weight; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
+    a.sh = bil_scale(h, H); a.sw = bil_scale(w, W);
+    const int Kc = ((Cf + Cl + 1 + 3) / 4) * 4;
+    const int64_t P = (int64_t)N * H * W;
+    hipLaunchKernelGGL(mc_seg_head_kernel, dim3((unsigned)uda_cdiv(P, 128)), dim3(256), (size_t)4 * Kc * sizeof(float), (hipStream_t)stream, a);
+    UDA_LAUNCH_CHECK("mc_seg_head");
     return 0;
 }
 

@@ -109,6 +109,19 @@ class DomainSplit:
         for hf, n0, n1 in self._halves(N):
             self.K.upsample_fwd(_rows(x, N, n0, n1), n1 - n0, h, w, _rows(out, N, n0, n1), H, W, stats[hf])
 
+    def upsample_stats(self, x, N, h, w, H, W, stats):
+        if stats.dim() == 3:
+            return self.K.upsample_stats(x, N, h, w, H, W, stats)
+        for hf, n0, n1 in self._halves(N):
+            self.K.upsample_stats(_rows(x, N, n0, n1), n1 - n0, h, w, H, W, stats[hf])
+
+    def mc_seg_head(self, feature, N, h, w, low, bnd, H, W, scale, shift, act, mask, mask_scale, wgt, bias, out):
+        if scale.dim() == 1:
+            return self.K.mc_seg_head(feature, N, h, w, low, bnd, H, W, scale, shift, act, mask, mask_scale, wgt, bias, out)
+        for hf, n0, n1 in self._halves(N):          # per-half coefficients [2, C]; the low-level rows are shared
+            self.K.mc_seg_head(_rows(feature, N, n0, n1), n1 - n0, h, w, low, _rows(bnd, N, n0, n1), H, W, scale[hf], shift[hf], act,
+                               None if mask is None else _rows(mask, N, n0, n1), mask_scale, wgt, bias, _rows(out, N, n0, n1))
+
     def bn_apply(self, src: Act, out, residual=None):
         if not src.split:
             return self.K.bn_apply(src, out, residual)

@@ -27,6 +27,9 @@ from typing import Dict, Optional
 
 import torch
 
+import os as _os
+
+_MC_VIRTUAL = _os.environ.get("UDA_CLR_MC_VIRTUAL", "1") != "0"      # A/B switch: stochastic passes without the x_feature matrix
 POISON_BUFFERS = False      # tests/test_generator_gpu.py sets it: every fp32 work matrix starts as NaN / Inf / huge values
 
 from .acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, BNRec, nchw_view, round4
@@ -720,10 +723,20 @@ class GeneratorEngine:
             K.conv(Act(tmp, N, H4, W4), self._w(ctx, "decoder.last_conv_boundary.0.weight", "low_ohwi"), 3, 1, D["y0"])
             del tmp
         p05 = DROPOUT["aspp.dropout"]
-        # one x_feature buffer for all passes: its 48 low-level channels do not depend on a dropout mask and are written once
-        xf = self._empty(x, reps * P4, 308)
-        for r in range(reps):
-            K.bn_apply(lo, xf[r * P4:(r + 1) * P4, 256:304], None)
+        # The 305-channel x_feature matrix of a stochastic pass feeds only the BatchNorm(305) statistics and the 305 -> 2 head.  It is
+        # not written (``virtual``): the statistics of its 256 upsampled channels come from an interpolation pass without a store
+        # (uda_upsample_fwd_stats, out = NULL), those of the 48 low-level channels from the un-repeated [P4, 48] rows (once per copy),
+        # the boundary channel's from its own column, and the head interpolates the upsampled channels on the fly (uda_mc_seg_head).
+        virtual = hasattr(K, "mc_seg_head") and 256 % (self.C_FEAT // 4) == 0 and _MC_VIRTUAL
+        if virtual:
+            lo_rows = self._empty(x, P4, 48)
+            K.bn_apply(lo, lo_rows, None)
+            xf = None
+        else:
+            # one x_feature buffer for all passes: its 48 low-level channels do not depend on a dropout mask and are written once
+            xf = self._empty(x, reps * P4, 308)
+            for r in range(reps):
+                K.bn_apply(lo, xf[r * P4:(r + 1) * P4, 256:304], None)
         for ps in range(passes):
             mk = None if masks is None else masks[ps]
             ctx.arena = _Arena(x, STAT_SLOTS * 2 * (256 + 256 + 305) * (2 if self.tn else 1))
@@ -739,8 +752,10 @@ class GeneratorEngine:
                            feature[r * P16:(r + 1) * P16], None)
             st305 = self._stats(ctx, 305, True)
             fused_up = 256 % (feature.shape[1] // 4) == 0
-            K.upsample_fwd(feature, N2, H16, W16, xf[:, 0:256], H4, W4, **({"stats": st305} if fused_up else {}))
-            xbu = Act(xf[:, :304], N2, H4, W4)
+            if virtual:
+                K.upsample_stats(feature, N2, H16, W16, H4, W4, st305)
+            else:
+                K.upsample_fwd(feature, N2, H16, W16, xf[:, 0:256], H4, W4, **({"stats": st305} if fused_up else {}))
             yb1 = self._empty(x, reps * P4, 256)
             st = self._stats(ctx, 256, True)
             # the low-level part of conv0 (y0) does not depend on a dropout mask: shared by all passes and repetitions
@@ -752,17 +767,28 @@ class GeneratorEngine:
             K.conv(b1, self._w(ctx, "decoder.last_conv_boundary.4.weight", "ohwi"), 3, 1, yb2, stats=st)
             m, ms = self._mask(x, "decoder.last_conv_boundary.7", reps * P4, 256, N2, H4, W4, True, mk)
             b2 = self._bn_act(ctx, "decoder.last_conv_boundary.5", yb2, N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
-            K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1, xf[:, 304:305],
+            bnd = self._buf(x, reps * P4, 1) if virtual else xf[:, 304:305]
+            K.conv(b2, self._w(ctx, "decoder.last_conv_boundary.8.weight", "ohwi"), 1, 1, bnd,
                    bias=params["decoder.last_conv_boundary.8.bias"])
             st = st305
-            if fused_up:
-                K.colstats_window(xf[:, 256:305], st, 256, **({"N": N2} if self.tn else {}))
-            else:
-                K.colstats(xf[:, :305], st, **({"N": N2} if self.tn else {}))
             m, ms = self._mask(x, "decoder.last_conv.2", reps * P4, 305, N2, H4, W4, True, mk)
-            sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
             x1b = self._buf(x, reps * P4, 2)
-            K.conv(sa, self._w(ctx, "decoder.last_conv.3.weight", "ohwi"), 1, 1, x1b, bias=params["decoder.last_conv.3.bias"])
+            if virtual:
+                split = self._split(ctx)
+                for r in range(reps):            # the low-level channels: every copy of the batch adds the same sums (TransNorm: its half's)
+                    K.colstats_window(lo_rows, st[r] if split else st, 256)
+                K.colstats_window(bnd, st, 304, **({"N": N2} if self.tn else {}))
+                coef = self._coef(ctx, x, 305, True)
+                self._bn(ctx, "decoder.last_conv.0", st, reps * P4, True, coef[0], coef[1], coef[2], coef[3], False, N2)
+                K.mc_seg_head(feature, N2, H16, W16, lo_rows, bnd, H4, W4, coef[0], coef[1], ACT_RELU, m, ms,
+                              self._w(ctx, "decoder.last_conv.3.weight", "ohwi"), params["decoder.last_conv.3.bias"], x1b)
+            else:
+                if fused_up:
+                    K.colstats_window(xf[:, 256:305], st, 256, **({"N": N2} if self.tn else {}))
+                else:
+                    K.colstats(xf[:, :305], st, **({"N": N2} if self.tn else {}))
+                sa = self._bn_act(ctx, "decoder.last_conv.0", xf[:, :305], N2, H4, W4, st, reps * P4, True, ACT_RELU, m, ms)
+                K.conv(sa, self._w(ctx, "decoder.last_conv.3.weight", "ohwi"), 1, 1, x1b, bias=params["decoder.last_conv.3.bias"])
             K.head_upsample_fwd(x1b, N2, H4, W4, out[ps * N2:(ps + 1) * N2])
             self._check_arena(ctx)
             ctx.arena = None

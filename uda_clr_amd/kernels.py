@@ -88,6 +88,7 @@ SYMBOLS = {
     "uda_colstats": (_I, [_P, _L, _L, _I, _I, _P, _P]),
     "uda_colstats_window": (_I, [_P, _L, _L, _I, _I, _P, _I, _P]),
     "uda_upsample_fwd_stats": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _P, _I, _P]),
+    "uda_mc_seg_head": (_I, [_P, _L, _I, _I, _I, _I, _P, _L, _I, _L, _P, _L, _I, _I, _P, _P, _I, _P, _L, _F, _P, _L, _P, _P, _L, _P]),
     "uda_bnbwd_reduce": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P]),
     "uda_bnbwd_finalize": (_I, [_P, _I, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "uda_bnbwd_apply": (_I, [_P, _L, C.POINTER(UdaSrc), _P, _P, _P, _P, _P, _L, _P, _L, _P]),
@@ -728,6 +729,36 @@ class HipKernels:
             self._ck(self.lib.uda_upsample_fwd_stats(p, ld, N, h, w, x.shape[1], o, ldo, H, W, stats.data_ptr(), stats.shape[2], self._stream()))
             return
         self._ck(self.lib.uda_upsample_fwd(p, ld, N, h, w, x.shape[1], o, ldo, H, W, self._stream()))
+
+    def upsample_stats(self, x, N, h, w, H, W, stats):
+        """per-channel (sum, sum of squares) of the bilinearly upsampled tensor ADDED into channels [0, C) of ``stats``; the
+        tensor itself is not written"""
+        self._dev(x)
+        p, ld = _mat(x, "x")
+        assert x.shape[0] == N * h * w and stats.dtype == torch.float64 and stats.is_contiguous()
+        assert stats.shape[:2] == (STAT_SLOTS, 2) and stats.shape[2] >= x.shape[1]
+        self._ck(self.lib.uda_upsample_fwd_stats(p, ld, N, h, w, x.shape[1], None, 0, H, W, stats.data_ptr(), stats.shape[2], self._stream()))
+
+    def mc_seg_head(self, feature, N, h, w, low, bnd, H, W, scale, shift, act, mask, mask_scale, wgt, bias, out):
+        """decoder.last_conv on the virtual x_feature = cat(up(feature), low rows (shared by the repeated batch), boundary):
+        ``uda_mc_seg_head``.  feature [N*h*w, Cf], low [P_low, Cl] with P_low | N*H*W, bnd [N*H*W, 1], wgt = relayout_ohwi of the
+        [2, C, 1, 1] weight, out [N*H*W, 2]."""
+        self._dev(feature)
+        fp, ldf = _mat(feature, "feature")
+        lp, ldl = _mat(low, "low")
+        P = N * H * W
+        Cf, Cl = feature.shape[1], low.shape[1]
+        Cc = Cf + Cl + 1
+        assert feature.shape[0] == N * h * w and P % low.shape[0] == 0 and bnd.shape == (P, 1) and out.shape == (P, 2)
+        assert bnd.stride(1) == 1 and out.stride(1) == 1 and wgt.is_contiguous() and wgt.shape[0] == 2 and wgt.numel() // 2 >= Cc
+        assert scale.is_contiguous() and shift.is_contiguous() and scale.numel() == Cc and bias.numel() == 2
+        mp, ldm = (None, 0)
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.shape == (P, Cc) and mask.stride(1) == 1
+            mp, ldm = mask.data_ptr(), mask.stride(0)
+        self._ck(self.lib.uda_mc_seg_head(fp, ldf, N, h, w, Cf, lp, ldl, Cl, low.shape[0], bnd.data_ptr(), bnd.stride(0), H, W,
+                                          scale.data_ptr(), shift.data_ptr(), int(act), mp, ldm, float(mask_scale), wgt.data_ptr(),
+                                          wgt.numel() // 2, bias.data_ptr(), out.data_ptr(), out.stride(0), self._stream()))
 
     def upsample_bwd(self, dout, N, H, W, dx, h, w):
         p, ld = _mat(dout, "dout")

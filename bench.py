@@ -191,16 +191,22 @@ class ConvTimer:
 
 def measured_traffic(args, mode):
     """(GB of HBM traffic per launch of the dominant kernel, file it comes from) out of the committed PMC passes of THIS
-    configuration and matrix mode (profiles/r02_*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per launch, profiles/pmc_traffic.py);
-    None for any other configuration.  It is NOT measured by this run - counters cannot be collected inside the timed region."""
-    if (args.workload, args.backbone, args.size, args.use_tn) != ("prototype_full", "mobilenet", 512, False):
+    configuration and matrix mode (profiles/r<round>_*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per launch, profiles/pmc_traffic.py;
+    the newest round that holds the file); None for any other configuration.  It is NOT measured by this run - counters cannot be
+    collected inside the timed region."""
+    import glob
+    kern = "x3" if mode == "bf16x3" else "ws"
+    if (args.workload, args.backbone, args.size, args.use_tn) == ("prototype_full", "mobilenet", 512, False):
+        pat = "r[0-9][0-9]_igemm_conv_%s_b%d_traffic.json" % (kern, args.batch)
+    elif (args.workload, args.backbone, args.size, args.use_tn) == ("source_only", "resnet", 512, False):
+        pat = "r[0-9][0-9]_resnet101_igemm_conv_%s_b%d_traffic.json" % (kern, args.batch)
+    else:
         return None
-    name = "r02_igemm_conv_%s_b%d_traffic.json" % ("x3" if mode == "bf16x3" else "ws", args.batch)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    if not os.path.exists(path):
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pat)))
+    if not found:
         return None
-    with open(path) as f:
-        return round(json.load(f)["hbm_bytes_per_launch"] / 1e9, 4), "profiles/" + name
+    with open(found[-1]) as f:
+        return round(json.load(f)["hbm_bytes_per_launch"] / 1e9, 4), "profiles/" + os.path.basename(found[-1])
 
 
 def cpu_baseline(workload, B, S, backbone="mobilenet"):

@@ -12,6 +12,11 @@ EXTRA="--mfma f32" PMC_MATCH='igemm_conv_ws_kernel<3' bash profiles/run_profiles
 echo "f32 pmc done"
 bash profiles/run_profiles.sh $OUT/other so rn tn > $OUT/other.log 2>&1 || { echo "so/rn/tn failed"; exit 1; }
 echo "so rn tn done"
+# ResNet-101 (BASELINE.json configs[4] shape on one GPU): PMC traffic of its dominant kernel (the bf16x3 multi-tap conv)
+EXTRA="--backbone resnet --workload source_only --batch 8" bash profiles/run_profiles.sh $OUT/rn pmc > $OUT/rn_pmc.log 2>&1 || { echo "resnet pmc failed"; exit 1; }
+echo "resnet pmc done"
+python3 bench.py --backbone resnet --workload source_only --batch 8 --steps 10 > $OUT/bench_rn_b8.log 2>&1 || { echo "bench rn failed"; exit 1; }
+grep '^{' $OUT/bench_rn_b8.log | tail -1 > $OUT/bench_rn_b8.json
 python3 bench.py > $OUT/bench_b16.log 2>&1 || { echo "bench b16 failed"; exit 1; }
 grep '^{' $OUT/bench_b16.log | tail -1 > $OUT/bench_b16.json
 python3 bench.py --batch 32 --steps 5 > $OUT/bench_b32.log 2>&1 || { echo "bench b32 failed"; exit 1; }

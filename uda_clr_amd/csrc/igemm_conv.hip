@@ -27,13 +27,16 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
-template <int TM, int TN, int WM, int WN>
+// PIPE: two LDS tile images and two register sets - chunk c is computed from one image while chunk c + 1 is staged into the other and
+// the global loads of chunk c + 2 are in flight, one barrier per chunk (round 3: the long-K project convs of the 32x32-map layers run
+// one workgroup per CU and sat at the global-load latency of every chunk: 12 chunks x 1.7 us against 0.47 us of MFMA work each).
+// PIPE = false: one image, loads one chunk ahead, two barriers per chunk (short K: fewer registers and half the LDS per workgroup).
+template <int TM, int TN, int WM, int WN, bool PIPE = false>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * IG_LD];
-    float* As = smem;
-    float* Bs = smem + BM * IG_LD;
+    constexpr int TILE = (BM + BN) * IG_LD;
+    __shared__ __attribute__((aligned(16))) float smem[(PIPE ? 2 : 1) * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -57,12 +60,15 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         ph[i] = (int)((q / W) % H);
     }
 
-    float4 areg[A_IT], breg[B_IT];
-    uint32_t amask[A_IT];
-    unsigned aok = 0;           // bit i: areg[i] holds a real load (else zero)
-    Xf4 xf;
-    int c_ci = 0;
-    bool c_kval = false;
+    struct Stg {                // one chunk of operand loads in registers + what its staging step needs
+        float4 areg[A_IT], breg[B_IT];
+        uint32_t amask[A_IT];
+        unsigned aok;           // bit i: areg[i] holds a real load (else zero)
+        Xf4 xf;
+        int c_ci;
+        bool c_kval;
+    };
+    Stg R0, R1;
 
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (P * a.src.ldx) * 4), 0x00020000);
@@ -71,7 +77,14 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
 
-    auto issue = [&](int chunk) {
+    auto issue = [&](int chunk, Stg& r) {
+        float4 (&areg)[A_IT] = r.areg;
+        float4 (&breg)[B_IT] = r.breg;
+        uint32_t (&amask)[A_IT] = r.amask;
+        unsigned& aok = r.aok;
+        Xf4& xf = r.xf;
+        int& c_ci = r.c_ci;
+        bool& c_kval = r.c_kval;
         const int k0 = chunk * IG_BK + kv;          // position in the weight row
         int t = 0, ci = k0;
         if (a.ksize >= 2) {
@@ -112,7 +125,13 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         }
     };
 
-    auto stage = [&]() {
+    auto stage = [&](Stg& r, float* As, float* Bs) {
+        float4 (&areg)[A_IT] = r.areg;
+        float4 (&breg)[B_IT] = r.breg;
+        uint32_t (&amask)[A_IT] = r.amask;
+        const unsigned aok = r.aok;
+        const Xf4& xf = r.xf;
+        const int c_ci = r.c_ci;
         const bool has_xf = a.src.scale != nullptr;
         const int act = a.src.act;
         const float ms = a.src.mask_scale;
@@ -159,12 +178,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     const int arow = wm * TM * 32 + (lane & 31), brow = wn * TN * 32 + (lane & 31);
     const int koff = 4 * (lane >> 5);
 
-    issue(0);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();            // every wave finished reading the previous chunk
-        stage();
-        __syncthreads();
-        if (c + 1 < nchunks) issue(c + 1);   // in flight under the MFMAs below
+    auto math = [&](const float* As, const float* Bs) {
 #pragma unroll
         for (int g = 0; g < IG_BK / 8; ++g) {
             float4 af[TM], bf[TN];
@@ -184,6 +198,42 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
                     }
                 }
             }
+        }
+    };
+    float* As = smem;
+    float* Bs = smem + BM * IG_LD;
+    if constexpr (PIPE) {
+        float* As1 = smem + TILE;
+        float* Bs1 = As1 + BM * IG_LD;
+        // chunk c lives in register set c & 1 and in image c & 1; chunks c + 1 (staged) and c + 2 (in flight) are ahead of the math
+        issue(0, R0);
+        if (nchunks > 1) issue(1, R1);
+        stage(R0, As, Bs);
+        if (nchunks > 2) issue(2, R0);
+        for (int c = 0; c < nchunks; c += 2) {
+            __syncthreads();        // image 0 holds chunk c; image 1 is no longer read
+            if (c + 1 < nchunks) {
+                stage(R1, As1, Bs1);
+                if (c + 3 < nchunks) issue(c + 3, R1);
+            }
+            math(As, Bs);
+            if (c + 1 < nchunks) {
+                __syncthreads();    // image 1 holds chunk c + 1; image 0 is no longer read
+                if (c + 2 < nchunks) {
+                    stage(R0, As, Bs);
+                    if (c + 4 < nchunks) issue(c + 4, R0);
+                }
+                math(As1, Bs1);
+            }
+        }
+    } else {
+        issue(0, R0);
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();            // every wave finished reading the previous chunk
+            stage(R0, As, Bs);
+            __syncthreads();
+            if (c + 1 < nchunks) issue(c + 1, R0);   // in flight under the MFMAs below
+            math(As, Bs);
         }
     }
 
@@ -427,7 +477,10 @@ static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     static_assert(BM == 128 || BM == 64, "tiles of 128 or 64 pixels");
     k.nMt = uda_cdiv(P, BM);
     k.nNt = uda_cdiv(k.Cout, BN);
-    hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
+    // long K: the pipelined form (two tile images, loads two chunks ahead); short K keeps the lean one (more workgroups per CU)
+    static const int pipe_min = getenv("UDA_CONV_PIPE_MIN_K") ? atoi(getenv("UDA_CONV_PIPE_MIN_K")) : 192;
+    if (k.Ktot >= pipe_min) hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN, true>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN, false>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
     UDA_LAUNCH_CHECK("igemm_conv");
     return 0;
 }

@@ -75,6 +75,17 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(a.src.mask ? a.src.mask : reinterpret_cast<const uint8_t*>(a.src.x)), 0,
         a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
+    // weights and per-channel coefficients through descriptors too: every load of a chunk is then an unconditional buffer load (a
+    // missing operand = an out-of-range offset = zeros), the loop has no branch around a load and the compiler can count vmcnt
+    // across the two register sets (with branches it waited vmcnt(0) before every staging step, i.e. for the NEWEST loads too:
+    // 1.2 us per chunk whatever the prefetch distance - measured, tests/tools/sweep_narrow.py)
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.Cout * a.Ktot * 4), 0x00020000);
+    const bool has_coef = a.src.scale != nullptr;
+    const __amdgpu_buffer_rsrc_t scres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_coef ? a.src.scale : a.src.x), 0, has_coef ? C * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_coef ? a.src.shift : a.src.x), 0, has_coef ? C * 4 : 0, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
 
     auto issue = [&](int chunk, Stg& r) {
@@ -105,7 +116,15 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
             dh = (th - a.cen) * a.dil;
             dw = (t - th * a.ksize - a.cen) * a.dil;
         }
-        uda_load_xf4(xf, a.src.scale, a.src.shift, ci, c_kval ? C : 0);
+        // coefficients of the 4 channels ci .. ci + 3 (identity where there is no transform / beyond C: those lanes are zeroed in
+        // the staging step anyway)
+        // (the descriptors' own range check returns zeros beyond C and without a transform; the staging step applies the
+        // coefficients only when there is a transform and zeroes the lanes beyond C itself - no condition, no select here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xf.sc[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scres, (ci + j) * 4, 0, 0));
+            xf.sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shres, (ci + j) * 4, 0, 0));
+        }
         aok = 0;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -114,14 +133,14 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
             // buffer loads: an out-of-range offset returns zeros (no branch around the load)
             const int q = (int)(m0 + lrow + 32 * i) + dh * W + dw;
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (q * (int)a.src.ldx + ci) * 4 : OOB, 0, 0));
-            amask[i] = a.src.mask ? __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * (int)a.src.ldm + ci : OOB, 0, 0) : 0x01010101u;
+            amask[i] = __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * (int)a.src.ldm + ci : OOB, 0, 0);      // (no mask: a zero-size descriptor)
             aok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + lrow + 32 * i;
-            breg[i] = (k0 < a.Ktot && n < a.Cout) ? uda_ld4(a.w + (int64_t)n * a.Ktot + k0)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (rows beyond Cout fall outside the descriptor; only the padded tail of the last chunk needs the select)
+            breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wres, k0 < a.Ktot ? (n * a.Ktot + k0) * 4 : OOB, 0, 0));
         }
     };
 
@@ -206,25 +225,23 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         float* As1 = smem + TILE;
         float* Bs1 = As1 + BM * IG_LD;
         // chunk c lives in register set c & 1 and in image c & 1; chunks c + 1 (staged) and c + 2 (in flight) are ahead of the math
+        // Every issue / stage below is UNCONDITIONAL: a chunk beyond the last one loads through out-of-range offsets (zeros, no
+        // memory access) and stages zeros into an image nobody reads.  With `if (c + 3 < nchunks) issue(...)` the number of loads in
+        // flight differs between the paths that meet at the next staging step, and the compiler's vmcnt has to cover the smaller
+        // count - i.e. it waits for the NEWEST register set too and the second set buys nothing (seen in the ISA: vmcnt(5) ... (0)).
         issue(0, R0);
-        if (nchunks > 1) issue(1, R1);
+        issue(1, R1);
         stage(R0, As, Bs);
-        if (nchunks > 2) issue(2, R0);
+        issue(2, R0);
         for (int c = 0; c < nchunks; c += 2) {
             __syncthreads();        // image 0 holds chunk c; image 1 is no longer read
-            if (c + 1 < nchunks) {
-                stage(R1, As1, Bs1);
-                if (c + 3 < nchunks) issue(c + 3, R1);
-            }
+            stage(R1, As1, Bs1);
+            issue(c + 3, R1);
             math(As, Bs);
-            if (c + 1 < nchunks) {
-                __syncthreads();    // image 1 holds chunk c + 1; image 0 is no longer read
-                if (c + 2 < nchunks) {
-                    stage(R0, As, Bs);
-                    if (c + 4 < nchunks) issue(c + 4, R0);
-                }
-                math(As1, Bs1);
-            }
+            __syncthreads();        // image 1 holds chunk c + 1; image 0 is no longer read
+            stage(R0, As, Bs);
+            issue(c + 4, R0);
+            if (c + 1 < nchunks) math(As1, Bs1);
         }
     } else {
         issue(0, R0);

@@ -2,7 +2,9 @@
 
 The generator has 5.8 M fp32 parameters (23 MB): per step ONE all-reduce of a flat gradient buffer
 (reduce-scatter + all-gather inside RCCL uses all 7 xGMI links of the fully connected node) is far
-below the step time, so there is a single bucket and no per-layer hook machinery.  BatchNorm
+below the step time, so there is a single bucket and no per-layer hook machinery (the generator is one
+autograd node per pass; its gradient is complete only after the T and the S pass).  The call is split into
+``start`` / ``finish`` so that Trainer_prototype_full overlaps it with its discriminator step.  BatchNorm
 statistics stay per rank - the reference uses plain nn.BatchNorm2d (deeplabv3.py:19-20).
 Prototype sums are all-reduced by ``AllReduceSum`` (differentiable: the adjoint of a sum
 all-reduce of per-rank partial sums is the identity on the already-global upstream gradient)."""
@@ -28,13 +30,25 @@ class FlatGradAllReduce:
 
     def all_reduce_mean(self):
         """Average ``.grad`` over ranks (missing grads count as zero)."""
-        w = world()
-        if w == 1:
-            return
+        self.finish(self.start())
+
+    def start(self):
+        """Gather the gradients into the flat buffer and START the sum all-reduce (asynchronous: on RCCL it runs on the
+        communicator's own stream behind the kernels already queued, so work issued next - the discriminator step of
+        Trainer_prototype_full, which does not read the generator's gradients - overlaps it).  Returns a handle for ``finish``;
+        the gradients must not be used in between."""
+        if world() == 1:
+            return None
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(w)
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self, handle):
+        """Wait for ``start``'s all-reduce and write the averaged gradients back into ``.grad``."""
+        if handle is None:
+            return
+        handle.wait()
+        self.flat.div_(world())
         have = [(p.grad, v) for p, v in zip(self.params, self.views) if p.grad is not None]
         if have:                                   # one multi-tensor copy instead of a launch per parameter
             torch._foreach_copy_([g for g, _ in have], [v for _, v in have])

@@ -297,11 +297,14 @@ class Trainer(TrainerBase):
             loss_aug = ops.consistency_loss(oT_aug, oT, self.mask_0, self.mask_1, self.epoch, self.aug_weight)
             loss_aug.backward()
             self.loss_aug = loss_aug.detach()
-        if self._reducers is not None:
-            self._reducers[0].all_reduce_mean()
-        self.optim_gen.step()
-        if hasattr(self.model_gen, 'note_params_changed'):
-            self.model_gen.note_params_changed()       # activations kept for the MC passes are stale now
+        # data parallel: the generator's gradient all-reduce is STARTED here and waited for after the discriminator step below - that
+        # step reads only the detached generator outputs and the discriminators' own weights, so ~12 ms of kernels overlap the
+        # collective; optim_gen.step() moves behind it (the discriminator step does not read the generator's parameters either)
+        pending = self._reducers[0].start() if self._reducers is not None else None
+        if self._reducers is None:
+            self.optim_gen.step()
+            if hasattr(self.model_gen, 'note_params_changed'):
+                self.model_gen.note_params_changed()       # activations kept for the MC passes are stale now
         # ---- discriminators on detached generator outputs (:471-517)
         self._set_requires_grad((gen,), False)
         oS, boundaryS = oS.detach(), boundaryS.detach()
@@ -312,6 +315,11 @@ class Trainer(TrainerBase):
         loss_D_diff.backward(inputs=dis_params)
         self._grad_mode((dis, dis2), "auto")
         del D_out1, D_out2, loss_all
+        if self._reducers is not None:
+            self._reducers[0].finish(pending)
+            self.optim_gen.step()
+            if hasattr(self.model_gen, 'note_params_changed'):
+                self.model_gen.note_params_changed()
         if self._reducers is not None:
             self._reducers[1].all_reduce_mean()
             self._reducers[2].all_reduce_mean()

@@ -63,7 +63,7 @@ int uda_relayout_dgrad(const float* w, int O, int I, int k, float* out, void* st
 /* depthwise [C][1][3][3] -> [9][C] */
 int uda_relayout_dw(const float* w, int C, float* out, void* stream);
 
-/* ---- dense stride-1 convolution as FP32-MFMA implicit GEMM (1x1, 3x3 with any dilation, and 2x2).
+/* ---- dense convolution (stride 1; stride 2 on the wide tiles) as MFMA implicit GEMM (1x1, 3x3 with any dilation, and 2x2).
  * Replaces F.conv2d at mobilenet.py:43,49,57, aspp.py:50-53,56,59, decoder.py:20,32,33,37,41 and,
  * with uda_relayout_dgrad weights, their input-gradient.
  *   y[p,co] = bias[co] + addend[p,co] + sum_{t,ci} u(p+off_t, ci) * w[co][t][ci]
@@ -89,7 +89,8 @@ typedef struct uda_conv_args {
     int64_t ldy;
     double* stats;         /* [UDA_STAT_SLOTS][2][Cout] or NULL */
     int32_t mfma;          /* UDA_MFMA_*: which matrix instructions the wide (MFMA-bound) tiles use; narrow kernels ignore it */
-    int32_t _pad3;
+    int32_t stride;        /* 0 | 1: stride 1.  2 (resnet.py:66,93; wide-tile kernels only: Cout > 96, K > 192, else an error):
+                              y, addend, stats live on the grid ((H-1)/2+1) x ((W-1)/2+1), row (n,oh,ow) is centred on src pixel (n,2oh,2ow) */
     const void* x3_src;    /* UDA_MFMA_BF16X3, when uda_conv_uses_x3(a): src packed by uda_x3_pack (transform already applied) ... */
     const void* x3_w;      /* ... and the weight rows w ([Cout] rows of the relayouted row length) packed by uda_x3_pack */
     void* workspace;       /* optional, 16-byte aligned: uda_conv_fwd_workspace_bytes(a) bytes let the bf16x3 kernel split the last, */
@@ -118,7 +119,7 @@ typedef struct uda_wgrad_args {
     float* workspace;
     uint64_t workspace_bytes;
     int32_t mfma;          /* UDA_MFMA_*, as in uda_conv_args_t */
-    int32_t _pad3;
+    int32_t stride;        /* as in uda_conv_args_t: 2 = dy lives on the strided output grid (wide-tile kernels only) */
     const void* x3_src;    /* UDA_MFMA_BF16X3, when uda_conv_wgrad_uses_x3(a): src packed by uda_x3_pack (the forward conv's packed form) ... */
     const void* x3_dy;     /* ... and dy ([P] rows of Cout values) packed by uda_x3_pack */
 } uda_wgrad_args_t;

@@ -93,23 +93,24 @@ def make_src(N, H, W, C, g, lazy=True, act=ACT_RELU, mask=False, bn=False, q1=Fa
 
 
 # ------------------------------------------------------------------------------------- cases
-def case_conv(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, bias=False, addend=False, stats=True, seed=0, origin=0):
+def case_conv(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, bias=False, addend=False, stats=True, seed=0, origin=0, stride=1):
     def run(dev):
         g = gen(seed)
         src = make_src(N, H, W, Cin, g, lazy, ACT_RELU6 if Cin % 8 else ACT_RELU, mask)
         w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
         b = torch.randn(Cout, generator=g) if bias else None
-        P = N * H * W
+        P = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
+        kw = {"stride": stride} if stride != 1 else {}
         ad = padded(P, Cout, g) if addend else None
         out_r = padded(P, Cout, g)
         st_r = torch.zeros(16, 2, Cout, dtype=torch.float64) if stats else None
-        SPEC.conv(src, SPEC.relayout_ohwi(w), k, dil, out_r, b, ad, st_r, origin=origin)
+        SPEC.conv(src, SPEC.relayout_ohwi(w), k, dil, out_r, b, ad, st_r, origin=origin, **kw)
         K = hip()
         out_h = to_dev(padded(P, Cout, g), dev)
         st_h = torch.zeros(16, 2, Cout, dtype=torch.float64, device=dev) if stats else None
         wl = K.relayout_ohwi(w.to(dev))
         errs = [rel(wl, SPEC.relayout_ohwi(w))]
-        K.conv(act_to(src, dev), wl, k, dil, out_h, None if b is None else b.to(dev), to_dev(ad, dev), st_h, origin=origin)
+        K.conv(act_to(src, dev), wl, k, dil, out_h, None if b is None else b.to(dev), to_dev(ad, dev), st_h, origin=origin, **kw)
         errs.append(rel(out_h, out_r))
         if stats:
             errs.append(rel(st_h.sum(0), st_r.sum(0)))
@@ -142,15 +143,16 @@ def case_dgrad(N, H, W, Cin, Cout, k, dil, accumulate=False, seed=1):
     return run
 
 
-def case_wgrad(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, seed=2, origin=0):
+def case_wgrad(N, H, W, Cin, Cout, k, dil, lazy=True, mask=False, seed=2, origin=0, stride=1):
     def run(dev):
         g = gen(seed)
         src = make_src(N, H, W, Cin, g, lazy, ACT_RELU, mask)
-        dy = padded(N * H * W, Cout, g)
+        dy = padded(N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1), Cout, g)
         ref = torch.empty(Cout, Cin, k, k)
-        SPEC.conv_wgrad(src, dy, k, dil, ref, origin=origin)
+        kw = {"stride": stride} if stride != 1 else {}
+        SPEC.conv_wgrad(src, dy, k, dil, ref, origin=origin, **kw)
         out = torch.empty(Cout, Cin, k, k, device=dev)
-        hip().conv_wgrad(act_to(src, dev), to_dev(dy, dev), k, dil, out, origin=origin)
+        hip().conv_wgrad(act_to(src, dev), to_dev(dy, dev), k, dil, out, origin=origin, **kw)
         return rel(out, ref), 3e-5
     return run
 
@@ -989,6 +991,19 @@ CASES += [
     ("dgrad1x1 1024<-256 P=8192 accumulate (x3 wide 1x1)", case_dgrad(8, 32, 32, 1024, 256, 1, 1, accumulate=True)),
     ("wgrad1x1 1024->256 P=8192 raw (x3 long-K 1x1)", case_wgrad(8, 32, 32, 1024, 256, 1, 1, lazy=False)),
     ("wgrad1x1 2048->512 P=4624 relu (x3 long-K 1x1)", case_wgrad(4, 34, 34, 2048, 512, 1, 1)),
+]
+# stride 2 on the wide tiles: the loaders walk the strided output grid (ResNet-101 layer2.0 / layer3.0 conv2, resnet.py:66, and their
+# weight gradients; the 1x1 form is the shortcut conv, resnet.py:93)
+CASES += [
+    ("conv3x3 s2 128->128 65x67 relu stats (strided grid, odd sizes)", case_conv(2, 65, 67, 128, 128, 3, 1, stride=2)),
+    ("conv3x3 s2 256->256 P=8192 raw addend no stats (tail split)", case_conv(8, 64, 64, 256, 256, 3, 1, lazy=False, addend=True, stats=False, stride=2)),
+    ("conv3x3 s2 dil2 160->200 mask ragged", case_conv(3, 41, 38, 160, 200, 3, 2, mask=True, stride=2)),
+    ("conv1x1 s2 256->512 33x40 relu bias", case_conv(2, 33, 40, 256, 512, 1, 1, bias=True, stride=2)),
+    ("conv1x1 s2 512->1024 raw (x3 wide 1x1)", case_conv(2, 64, 64, 512, 1024, 1, 1, lazy=False, stride=2)),
+    ("wgrad3x3 s2 128->128 65x67 relu", case_wgrad(2, 65, 67, 128, 128, 3, 1, stride=2)),
+    ("wgrad3x3 s2 256->256 P=16384 raw (x3)", case_wgrad(4, 128, 128, 256, 256, 3, 1, lazy=False, stride=2)),
+    ("wgrad3x3 s2 128->128 41 images of 20x20 (rows shorter than a chunk)", case_wgrad(41, 20, 20, 128, 128, 3, 1, stride=2)),
+    ("wgrad1x1 s2 256->512 33x40 mask", case_wgrad(2, 33, 40, 256, 512, 1, 1, mask=True, stride=2)),
 ]
 
 

@@ -117,14 +117,14 @@ class SpecKernels:
             return F.pad(u, (1, 0, 1, 0)) if origin else F.pad(u, (0, 1, 0, 1))
         return u
 
-    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
-        """out[p, co] = bias[co] + addend[p, co] + sum_{t, ci} u(p + off_t, ci) * w[co, t, ci];
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0, stride=1):
+        """out[p, co] = bias[co] + addend[p, co] + sum_{t, ci} u(stride * p + off_t, ci) * w[co, t, ci];
         ``w`` is the relayout_ohwi operand; stats (fp64 [2, Cout]) receives sum and sum of squares of the
         value before ``addend``."""
         Cin, Cout = src.C, out.shape[1]
         u = self._pad_taps(_nchw(transform(src), src.N, src.H, src.W), ksize, dil, origin)
         w4 = self._taps_channels(w, ksize * ksize, Cin).reshape(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
-        y = _rows(F.conv2d(u, w4, bias, 1, 0, dil if ksize == 3 else 1))
+        y = _rows(F.conv2d(u, w4, bias, stride, 0, dil if ksize == 3 else 1))
         if stats is not None:
             stats[0, 0] += y.double().sum(0)
             stats[0, 1] += (y.double() ** 2).sum(0)
@@ -132,11 +132,11 @@ class SpecKernels:
             y = y + addend
         out.copy_(y)
 
-    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
-        """dw[co, ci, kh, kw] = sum_p dy[p, co] * u(p + off_t, ci)   (OIHW result)."""
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0, stride=1):
+        """dw[co, ci, kh, kw] = sum_p dy[p, co] * u(stride * p + off_t, ci)   (OIHW result)."""
         u = self._pad_taps(_nchw(transform(src), src.N, src.H, src.W), ksize, dil, origin)
-        g = _nchw(dy, src.N, src.H, src.W)
-        res = torch.nn.grad.conv2d_weight(u, dw.shape, g, 1, 0, dil if ksize == 3 else 1)
+        g = _nchw(dy, src.N, (src.H - 1) // stride + 1, (src.W - 1) // stride + 1)
+        res = torch.nn.grad.conv2d_weight(u, dw.shape, g, stride, 0, dil if ksize == 3 else 1)
         dw.copy_(res)
 
     # ------------------------------------------------------------------ depthwise 3x3

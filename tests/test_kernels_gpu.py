@@ -70,3 +70,17 @@ def test_operands_beyond_the_32_bit_offsets_run_as_image_groups():
         a, b = res[(mode, "one")], res[(mode, "groups")]
         assert torch.equal(a[0], b[0])
         assert rel(b[1], a[1]) < 1e-6 and rel(b[2], a[2]) < 1e-5      # per-tile fp32 partials of the statistics shift with the tile origin
+
+
+def test_stride_two_is_refused_where_it_is_not_built():
+    """stride 2 lives in the wide-tile loaders only; the narrow kernels must say so instead of computing a stride-1 result"""
+    import kernel_cases
+    from uda_clr_amd.acts import Act
+    dev = torch.device("cuda:0")
+    K = kernel_cases.hip()
+    x = torch.randn(2 * 16 * 16, 64, device=dev)
+    w = K.relayout_ohwi(torch.randn(32, 64, 3, 3, device=dev))
+    with pytest.raises(RuntimeError, match="stride 2"):
+        K.conv(Act(x, 2, 16, 16), w, 3, 1, torch.empty(2 * 8 * 8, 32, device=dev), stride=2)
+    with pytest.raises(RuntimeError, match="stride 2"):
+        K.conv_wgrad(Act(x, 2, 16, 16), torch.randn(2 * 8 * 8, 32, device=dev), 3, 1, torch.empty(32, 64, 3, 3, device=dev), stride=2)

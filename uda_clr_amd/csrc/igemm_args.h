@@ -17,6 +17,7 @@ struct ConvKArgs {
     int nMt, nNt;
     int debug;     // diagnostics only (UDA_WS_DEBUG): bit0 skip MFMAs, bit1 skip loader work
     int x3;        // UDA_MFMA_BF16X3: wide tiles on the bf16 pipe by exact 3-way splitting (igemm_x3.hip)
+    int stride, Ho, Wo;   // output grid: pixel (n, oh, ow) reads the taps around input pixel (n, oh * stride, ow * stride); wide-tile kernels only
 };
 
 struct WgradKArgs {
@@ -28,6 +29,7 @@ struct WgradKArgs {
     float* slab;      // [S][Cout][Jtot]
     int nCot, nJt, chunks_per_split, nchunks;
     int x3;
+    int stride, Ho, Wo;   // grid of dy (see ConvKArgs); wide-tile kernels only
 };
 
 #define IG_BK 32

@@ -527,7 +527,8 @@ extern "C" uint64_t uda_conv_fwd_workspace_bytes(const uda_conv_args_t* a) {
     k.src = a->src; k.Cout = a->Cout; k.ksize = a->ksize; k.stats = a->stats;
     k.Kc = ((a->src.C + 3) / 4) * 4;
     k.Ktot = uda_k_row(a->src.C, a->ksize);
-    return conv_x3_workspace_bytes(k, (int64_t)a->src.N * a->src.H * a->src.W);
+    const int sd = a->stride <= 1 ? 1 : a->stride;
+    return conv_x3_workspace_bytes(k, (int64_t)a->src.N * ((a->src.H - 1) / sd + 1) * ((a->src.W - 1) / sd + 1));
 }
 
 extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
@@ -539,9 +540,15 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     UDA_REQUIRE(a->Cout > 0 && a->dil >= 1 && a->y && a->w, "uda_conv_fwd: bad args");
     UDA_REQUIRE(uda_aligned16(a->w), "uda_conv_fwd: weights must be 16-byte aligned");
     UDA_REQUIRE(a->ldy >= a->Cout, "uda_conv_fwd: ldy < Cout");
-    const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
+    // stride 2 (resnet.py:66 conv2 of the first bottleneck of layer2 / layer3, :93 their 1x1 shortcut): output pixel (n, oh, ow) is
+    // centred on input pixel (n, 2 oh, 2 ow); P counts OUTPUT rows from here on
+    const int sd = a->stride <= 1 ? 1 : a->stride;
+    UDA_REQUIRE(sd <= 2, "uda_conv_fwd: stride must be 1 or 2");
+    const int Ho = (a->src.H - 1) / sd + 1, Wo = (a->src.W - 1) / sd + 1;
+    const int64_t Pin = (int64_t)a->src.N * a->src.H * a->src.W, P = (int64_t)a->src.N * Ho * Wo;
     ConvKArgs k;
     k.src = a->src;
+    k.stride = sd; k.Ho = Ho; k.Wo = Wo;
     k.w = a->w;
     k.Cout = a->Cout;
     k.ksize = a->ksize;
@@ -557,9 +564,14 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     k.stats = a->stats;
     k.debug = 0;
     k.x3 = a->mfma == UDA_MFMA_BF16X3;
-    UDA_REQUIRE((P + 128) * a->src.ldx < ((int64_t)1 << 29) && (P + 128) * (a->src.mask ? a->src.ldm : 1) < ((int64_t)1 << 31),
+    UDA_REQUIRE((Pin + 128) * a->src.ldx < ((int64_t)1 << 29) && (Pin + 128) * (a->src.mask ? a->src.ldm : 1) < ((int64_t)1 << 31),
                 "uda_conv_fwd: operand too large for 32-bit byte offsets (P * ld must stay below 2^29 elements)");
     int e;
+    if (sd != 1) {       // only the wide-tile kernels walk a strided output grid
+        const bool wide = conv_is_wide(a, k.Kc, k.Ktot) && a->Cout > 96 && !(k.Ktot <= 192 || (a->ksize >= 2 && k.Kc < IG_BK));
+        UDA_REQUIRE(wide, "uda_conv_fwd: stride 2 is built on the wide-tile kernels only (Cout > 96, K > 192)");
+        return (k.x3 && conv_x3_eligible(k)) ? launch_conv_x3(k, P, a->x3_src, a->x3_w, st, a->workspace, a->workspace_bytes) : launch_conv_ws(k, P, st);
+    }
     if (a->Cout == 1 && !a->src.scale && !a->src.mask && a->src.act == ACT_NONE && !a->stats && k.Ktot >= 1024) {
         hipLaunchKernelGGL(conv_cout1_kernel, dim3(uda_cdiv(P, 4)), dim3(256), 0, st, k);
         UDA_LAUNCH_CHECK("conv_cout1");
@@ -825,7 +837,8 @@ extern "C" uint64_t uda_conv_wgrad_workspace_bytes(int64_t P, int Cout, int Cin,
 
 extern "C" int uda_conv_wgrad_uses_x3(const uda_wgrad_args_t* a) {
     if (!a || a->mfma != UDA_MFMA_BF16X3 || a->ksize < 1 || a->ksize > 3) return 0;
-    const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
+    const int sd = a->stride <= 1 ? 1 : a->stride;
+    const int64_t P = (int64_t)a->src.N * ((a->src.H - 1) / sd + 1) * ((a->src.W - 1) / sd + 1);      // pixels of dy
     const WgradPlan p = wgrad_plan(P, a->Cout, a->src.C, a->ksize);
     const bool wide = p.bm == 256 || (p.bm == 128 && p.bn == 128);
     return wide && wgrad_x3_eligible(a->src.C, a->Cout, a->ksize, P) ? 1 : 0;
@@ -839,12 +852,19 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     UDA_REQUIRE(a->ksize != 2 || a->origin == 0 || a->origin == 1, "uda_conv_wgrad: origin must be 0 or 1 for ksize 2");
     UDA_REQUIRE(a->dy && uda_aligned16(a->dy) && a->lddy % 4 == 0 && a->lddy >= ((a->Cout + 3) / 4) * 4,
                 "uda_conv_wgrad: dy must be 16-byte aligned with lddy %% 4 == 0 and >= round4(Cout)");
-    const int64_t P = (int64_t)a->src.N * a->src.H * a->src.W;
+    // stride 2: dy lives on the output grid, its pixel (n, oh, ow) pairs with source pixel (n, 2 oh, 2 ow); P = pixels of dy
+    const int sd = a->stride <= 1 ? 1 : a->stride;
+    UDA_REQUIRE(sd <= 2, "uda_conv_wgrad: stride must be 1 or 2");
+    const int Ho = (a->src.H - 1) / sd + 1, Wo = (a->src.W - 1) / sd + 1;
+    const int64_t P = (int64_t)a->src.N * Ho * Wo;
     const WgradPlan p = wgrad_plan(P, a->Cout, a->src.C, a->ksize);
     UDA_REQUIRE(a->workspace && a->workspace_bytes >= uda_conv_wgrad_workspace_bytes(P, a->Cout, a->src.C, a->ksize),
                 "uda_conv_wgrad: workspace too small");
+    UDA_REQUIRE(sd == 1 || p.bm == 256 || (p.bm == 128 && p.bn == 128),
+                "uda_conv_wgrad: stride 2 is built on the wide-tile kernels only (Cout > 64, K > 64)");
     WgradKArgs k;
     k.src = a->src;
+    k.stride = sd; k.Ho = Ho; k.Wo = Wo;
     k.dy = a->dy;
     k.lddy = a->lddy;
     k.Cout = a->Cout;

@@ -47,7 +47,8 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
     const int lid = uda_xcd_remap(blockIdx.x, a.nMt * a.nNt);
     const int mt = lid / a.nNt, nt = lid % a.nNt;
     const int H = a.src.H, W = a.src.W, C = a.src.C;
-    const int64_t P = (int64_t)a.src.N * H * W;
+    const int64_t P = (int64_t)a.src.N * a.Ho * a.Wo;          // output rows (= input pixels at stride 1)
+    const int64_t Pin = (int64_t)a.src.N * H * W;
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
     const int nchunks = (a.Ktot + IG_BK - 1) / IG_BK;
@@ -73,8 +74,10 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
         for (int i = 0; i < A_IT; ++i) {
             const int64_t p = m0 + lrow + 32 * i;
             const bool ok = p < P;
-            const int q = ok ? (int)p : 0;
-            const int pw = q % W, ph = (q / W) % H;
+            const int qo = ok ? (int)p : 0;
+            // output pixel (n, oh, ow) is centred on input pixel (n, oh * stride, ow * stride)
+            const int pw = (qo % a.Wo) * a.stride, ph = ((qo / a.Wo) % a.Ho) * a.stride;
+            const int q = ((qo / (a.Wo * a.Ho)) * H + ph) * W + pw;
             rowoff[i] = q * ldx;
             rowoffm[i] = q * ldm;
             unsigned vm = 0;
@@ -102,10 +105,10 @@ __global__ __launch_bounds__((MW + 4) * 64) void igemm_conv_ws_kernel(ConvKArgs 
     // Operand loads go through buffer descriptors: a lane whose tap falls outside the image (or beyond the channels)
     // presents an out-of-range offset and the hardware returns zeros - no branch, no select, no memory access.
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (P * a.src.ldx) * 4), 0x00020000);
+        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (Pin * a.src.ldx) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(a.src.mask ? a.src.mask : reinterpret_cast<const uint8_t*>(a.src.x)), 0,
-        a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
+        a.src.mask ? (int)min((int64_t)0x7fffffff, Pin * a.src.ldm) : 0, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
 
     auto issue = [&]() {       // loads of the chunk at (t_cur, ci_cur); then advance by BK
@@ -390,8 +393,8 @@ static int launch_ws_tn(ConvKArgs& k, int64_t P, int tn, bool tall, bool low, hi
 }
 
 int launch_conv_ws(ConvKArgs& k, int64_t P, hipStream_t st) {
-    const int64_t lim = (int64_t)1 << 31;
-    UDA_REQUIRE((P + 128) * k.src.ldx < lim / 4 && (P + 128) * (k.src.mask ? k.src.ldm : 1) < lim && (int64_t)(k.Cout + 320) * k.Ktot < lim,
+    const int64_t lim = (int64_t)1 << 31, Pin = (int64_t)k.src.N * k.src.H * k.src.W;      // (P: output rows)
+    UDA_REQUIRE((Pin + 128) * k.src.ldx < lim / 4 && (Pin + 128) * (k.src.mask ? k.src.ldm : 1) < lim && (int64_t)(k.Cout + 320) * k.Ktot < lim,
                 "uda_conv_fwd: operand too large for the 32-bit element offsets of the wide-tile kernel");
     // Tile width BN = 64*TN chosen by a wave-quantisation model: workgroups run one per CU, a K-chunk
     // costs ~TN MFMA-units, so time ~ ceil(#tiles / 256 CUs) * TN.  E.g. Cout = 304 at P = 262144 ->
@@ -432,7 +435,8 @@ __global__ __launch_bounds__(BIG ? 768 : 512) void igemm_wgrad_ws_kernel(WgradKA
     const int cot = blockIdx.x / a.nJt, jt = blockIdx.x % a.nJt;
     const int split = blockIdx.y;
     const int H = a.src.H, W = a.src.W, C = a.src.C;
-    const int64_t P = (int64_t)a.src.N * H * W;
+    const int Ho = a.Ho, Wo = a.Wo, sd = a.stride;              // grid of dy; its pixel (n, oh, ow) pairs with source pixel (n, oh * sd, ow * sd)
+    const int64_t P = (int64_t)a.src.N * Ho * Wo, Pin = (int64_t)a.src.N * H * W;
     const int c0 = split * a.chunks_per_split;
     const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
 
@@ -462,17 +466,19 @@ __global__ __launch_bounds__(BIG ? 768 : 512) void igemm_wgrad_ws_kernel(WgradKA
     uint32_t bmask[NP];
     unsigned bok = 0;
     // per staged pixel row: pixel index and (h, w), advanced by 32 pixels per chunk without divisions
-    int pp[NP], hh0[NP], ww0[NP];
+    int pp[NP], hh0[NP], ww0[NP], sp[NP];                       // dy pixel, its (oh, ow), source pixel
     if (loader) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int64_t p = (int64_t)c0 * WG_BKP + pr + i * RP;
             const int q = (int)(p < P ? p : 0);
             pp[i] = (int)p;
-            ww0[i] = q % W;
-            hh0[i] = (q / W) % H;
+            ww0[i] = q % Wo;
+            hh0[i] = (q / Wo) % Ho;
+            sp[i] = ((q / (Wo * Ho)) * H + hh0[i] * sd) * W + ww0[i] * sd + (int)(p - q);      // (beyond P: never read)
         }
     }
+    const int rowstep = sd * (W - Wo), imgstep = (H - sd * Ho) * W;      // source-pixel corrections at a row / image wrap (0 at stride 1)
     const int ldx = (int)a.src.ldx, ldm = (int)a.src.ldm, lddy = (int)a.lddy;
     const int tapoff = dh * W + dw;
 
@@ -481,10 +487,10 @@ __global__ __launch_bounds__(BIG ? 768 : 512) void igemm_wgrad_ws_kernel(WgradKA
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.dy), 0, (int)min((int64_t)0x7fffffff, (P * a.lddy) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (P * a.src.ldx) * 4), 0x00020000);
+        const_cast<float*>(a.src.x), 0, (int)min((int64_t)0x7fffffff, (Pin * a.src.ldx) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(a.src.mask ? a.src.mask : reinterpret_cast<const uint8_t*>(a.src.x)), 0,
-        a.src.mask ? (int)min((int64_t)0x7fffffff, P * a.src.ldm) : 0, 0x00020000);
+        a.src.mask ? (int)min((int64_t)0x7fffffff, Pin * a.src.ldm) : 0, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
     auto issue = [&]() {
         bok = 0;
@@ -493,18 +499,23 @@ __global__ __launch_bounds__(BIG ? 768 : 512) void igemm_wgrad_ws_kernel(WgradKA
             const bool pin = pp[i] < (int)P;
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                 yres, (pin && co < a.Cout) ? (pp[i] * lddy + co) * 4 : OOB, 0, 0));
-            const int hh = hh0[i] + dh, ww = ww0[i] + dw;
+            const int hh = hh0[i] * sd + dh, ww = ww0[i] * sd + dw;
             const bool ok = jok && pin && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            const int q = pp[i] + tapoff;
+            const int q = sp[i] + tapoff;
             breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (q * ldx + ci) * 4 : OOB, 0, 0));
             if (XF == 2) bmask[i] = __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * ldm + ci : OOB, 0, 0);
             bok |= (ok ? 1u : 0u) << i;
             // advance this row by one chunk (32 pixels)
             pp[i] += WG_BKP;
+            sp[i] += WG_BKP * sd;
             ww0[i] += WG_BKP;
-            while (ww0[i] >= W) {
-                ww0[i] -= W;
-                if (++hh0[i] >= H) hh0[i] = 0;
+            while (ww0[i] >= Wo) {
+                ww0[i] -= Wo;
+                sp[i] += rowstep;
+                if (++hh0[i] >= Ho) {
+                    hh0[i] = 0;
+                    sp[i] += imgstep;
+                }
             }
         }
     };

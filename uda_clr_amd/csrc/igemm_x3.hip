@@ -186,6 +186,7 @@ struct X3KArgs {
     const uint32_t* xa;   // packed activations [P][nbA][3][16]
     const uint32_t* xw;   // packed weights [Cout][nchunks][3][16]
     int N, H, W, nbA;
+    int stride, Ho, Wo;   // output grid: row (n, oh, ow) is centred on input pixel (n, oh * stride, ow * stride)
     int Cout, ksize, dil, cen, nchunks;
     const float* bias;
     const float* addend;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
     const int lid = TAIL ? a.tile_off + (int)blockIdx.x / a.ksplit : uda_xcd_remap(blockIdx.x, a.ntiles_main);
     const int mt = lid / a.nNt, nt = lid % a.nNt;
     const int H = a.H, W = a.W;
-    const int64_t P = (int64_t)a.N * H * W;
+    const int64_t P = (int64_t)a.N * a.Ho * a.Wo;                // output rows (= input pixels at stride 1)
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
     const int T = a.ksize * a.ksize;
@@ -256,9 +257,9 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             const int u = lt + 256 * i, row = unit_row(u), part = u - row * 6;
             const int64_t p = m0 + row;
             const bool ok = p < P;
-            const int q = ok ? (int)p : 0;
-            const int pw = q % W, ph = (q / W) % H;
-            aoff[i] = q * rowA16 + part;
+            const int qo = ok ? (int)p : 0;
+            const int pw = (qo % a.Wo) * a.stride, ph = ((qo / a.Wo) % a.Ho) * a.stride;
+            aoff[i] = (((qo / (a.Wo * a.Ho)) * H + ph) * W + pw) * rowA16 + part;
             unsigned vm = 0;
             if (ok) {
                 if (KS == 3) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(768) void igemm_conv_x3_kernel(X3KArgs a) {
             boff[i] = n * (a.nchunks * 6) + part;
         }
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(a.xa), 0, (int)min((int64_t)0x7fffffff, P * rowA16 * 16), 0x00020000);
+        const_cast<uint32_t*>(a.xa), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.N * H * W * rowA16 * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(a.xw), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.Cout * a.nchunks * 96), 0x00020000);
     auto issue = [&](uint4 (&ar)[A_U], uint4 (&br)[B_U]) {
@@ -711,11 +712,13 @@ int launch_conv_x3(ConvKArgs& k, int64_t P, const void* x3_src, const void* x3_w
     const int nbA = x3_nb(k.src.C), nch = uda_cdiv(k.Ktot, X3_BK);
     UDA_REQUIRE(x3_src && x3_w && uda_aligned16(x3_src) && uda_aligned16(x3_w),
                 "uda_conv_fwd (bf16x3): the packed operands x3_src / x3_w are missing (uda_x3_pack; uda_conv_uses_x3 tells when they are needed)");
-    UDA_REQUIRE((P + 256) * nbA * 6 < lim / 16 && (int64_t)(k.Cout + 320) * nch * 6 < lim / 16,
+    const int64_t Pin = (int64_t)k.src.N * k.src.H * k.src.W;      // (P: output rows)
+    UDA_REQUIRE((Pin + 256) * nbA * 6 < lim / 16 && (int64_t)(k.Cout + 320) * nch * 6 < lim / 16,
                 "uda_conv_fwd (bf16x3): operand too large for the 32-bit offsets of the wide-tile kernel");
     X3KArgs x;
     x.xa = reinterpret_cast<const uint32_t*>(x3_src); x.xw = reinterpret_cast<const uint32_t*>(x3_w);
     x.N = k.src.N; x.H = k.src.H; x.W = k.src.W; x.nbA = nbA;
+    x.stride = k.stride; x.Ho = k.Ho; x.Wo = k.Wo;
     x.Cout = k.Cout; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen; x.nchunks = nch;
     x.bias = k.bias; x.addend = k.addend; x.ld_add = k.ld_add; x.y = k.y; x.ldy = k.ldy; x.stats = k.stats;
     if (k.ksize >= 2 && k.Cout <= 64) return launch_x3<3, 1, 256>(x, P, st);      // input gradient towards a narrow tensor (decoder low-level branch)
@@ -755,6 +758,7 @@ struct X3WgArgs {
     const uint32_t* xdy;  // packed dy  [P][nbCo][3][16]
     const uint32_t* xs;   // packed (transformed) source [P][nbC][3][16]
     int N, H, W, nbCo, nbC;
+    int stride, Ho, Wo;   // grid of dy: its pixel (n, oh, ow) pairs with source pixel (n, oh * stride, ow * stride)
     int Cout, Jtot, Kc, ksize, dil, cen;
     float* slab;          // [S][Cout][Jtot]
     int nCot, nJt, cps, nchunks;
@@ -772,8 +776,8 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = __builtin_amdgcn_readfirstlane(wave) >= MW;
     const int cot = blockIdx.x / a.nJt, jt = blockIdx.x % a.nJt, split = blockIdx.y;
-    const int H = a.H, W = a.W;
-    const int64_t P = (int64_t)a.N * H * W;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, sd = a.stride;
+    const int64_t P = (int64_t)a.N * Ho * Wo;                    // pixels of dy
     const int c0 = split * a.cps, c1 = min(a.nchunks, c0 + a.cps), n = c1 - c0;
 
     constexpr int OOB = 0x7ffffff0;
@@ -784,12 +788,14 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
     int aoff[UA], boff[UB], btap[UB];                   // 16-byte unit offsets relative to the pixel row; packed (dh, dw) of the unit's tap
     unsigned aval = 0, bval = 0;                        // per-unit "block exists" bits
     uint4 ar0[UA], br0[UB], ar1[UA], br1[UB];
-    int pcur = c0 * 16 + ps, hcur = 0, wcur = 0;
+    int pcur = c0 * 16 + ps, hcur = 0, wcur = 0, scur = 0;      // dy pixel, its (oh, ow), the source pixel it pairs with
     const int rowDy = a.nbCo * 6, rowS = a.nbC * 6;
+    const int rowstep = sd * (W - Wo), imgstep = (H - sd * Ho) * W;      // source-pixel corrections at a row / image wrap (0 at stride 1)
     {
         const int q = (int)(pcur < P ? pcur : 0);
-        wcur = q % W;
-        hcur = (q / W) % H;
+        wcur = q % Wo;
+        hcur = (q / Wo) % Ho;
+        scur = ((q / (Wo * Ho)) * H + hcur * sd) * W + wcur * sd;
 #pragma unroll
         for (int i = 0; i < UA; ++i) {
             const int e = li + 16 * i, b = e / 6, part = e - 6 * b;
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(a.xdy), 0, (int)min((int64_t)0x7fffffff, P * rowDy * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(a.xs), 0, (int)min((int64_t)0x7fffffff, P * rowS * 16), 0x00020000);
+        const_cast<uint32_t*>(a.xs), 0, (int)min((int64_t)0x7fffffff, (int64_t)a.N * H * W * rowS * 16), 0x00020000);
     auto issue = [&](uint4 (&ar)[UA], uint4 (&br)[UB]) {
         const bool pin = pcur < (int)P;
 #pragma unroll
@@ -826,15 +832,20 @@ __global__ __launch_bounds__(768) void igemm_wgrad_x3_kernel(X3WgArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < UB; ++i) {
-            const int hh = hcur + (btap[i] >> 16), ww = wcur + (int)(short)(btap[i] & 0xffff);
+            const int hh = hcur * sd + (btap[i] >> 16), ww = wcur * sd + (int)(short)(btap[i] & 0xffff);
             const bool okb = pin && ((bval >> i) & 1u) && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(sres, okb ? (pcur * rowS + boff[i]) * 16 : OOB, 0, 0));
+            br[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(sres, okb ? (scur * rowS + boff[i]) * 16 : OOB, 0, 0));
         }
         pcur += 16;                 // next chunk: 16 pixels on
+        scur += 16 * sd;
         wcur += 16;
-        while (wcur >= W) {
-            wcur -= W;
-            if (++hcur >= H) hcur = 0;
+        while (wcur >= Wo) {
+            wcur -= Wo;
+            scur += rowstep;
+            if (++hcur >= Ho) {
+                hcur = 0;
+                scur += imgstep;
+            }
         }
     };
     auto stage = [&](const uint4 (&ar)[UA], const uint4 (&br)[UB], char* buf) {
@@ -952,7 +963,8 @@ int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_sr
                 "uda_conv_wgrad (bf16x3): the packed operands x3_src / x3_dy are missing (uda_x3_pack; uda_conv_wgrad_uses_x3)");
     const int64_t lim = (int64_t)1 << 31;
     const int nbCo = x3_nb(k.Cout), nbC = x3_nb(k.src.C);
-    UDA_REQUIRE((P + 64) * nbCo * 6 < lim / 16 && (P + 64 + 4 * k.src.W * k.dil) * nbC * 6 < lim / 16,
+    const int64_t Pin = (int64_t)k.src.N * k.src.H * k.src.W;      // (P: pixels of dy)
+    UDA_REQUIRE((P + 64) * nbCo * 6 < lim / 16 && (Pin + 64 + 4 * k.src.W * k.dil) * nbC * 6 < lim / 16,
                 "uda_conv_wgrad (bf16x3): operand too large for the 32-bit offsets of the wide-tile kernel");
     // tiles (Cout x J): 256 x 256 for wide outputs; 128 x 256 otherwise (128 x 128 tiles would stage 64 B per MFMA clock and CU and
     // are load-bound); 128 x 128 only for short J
@@ -962,6 +974,7 @@ int launch_wgrad_x3(const WgradKArgs& k, int64_t P, int S_max, const void* x3_sr
     X3WgArgs x;
     x.xdy = reinterpret_cast<const uint32_t*>(x3_dy); x.xs = reinterpret_cast<const uint32_t*>(x3_src);
     x.N = k.src.N; x.H = k.src.H; x.W = k.src.W; x.nbCo = nbCo; x.nbC = nbC;
+    x.stride = k.stride; x.Ho = k.Ho; x.Wo = k.Wo;
     x.Cout = k.Cout; x.Jtot = k.Jtot; x.Kc = k.Kc; x.ksize = k.ksize; x.dil = k.dil; x.cen = k.cen;
     x.slab = k.slab;
     x.nCot = uda_cdiv(k.Cout, BM); x.nJt = uda_cdiv(k.Jtot, BN);

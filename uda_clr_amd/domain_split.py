@@ -49,13 +49,13 @@ class DomainSplit:
                    None if a.mask is None else _rows(a.mask, a.N, n0, n1), a.mask_scale, a.bn, a.meta)
 
     # ------------------------------------------------------------------ forward producers
-    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0, stride=1):
         if not src.split and (stats is None or stats.dim() == 3):
-            return self.K.conv(src, w, ksize, dil, out, bias, addend, stats, origin=origin)
+            return self.K.conv(src, w, ksize, dil, out, bias, addend, stats, origin=origin, stride=stride)
         for h, n0, n1 in self._halves(src.N):
             self.K.conv(self._sub(src, h, n0, n1), w, ksize, dil, _rows(out, src.N, n0, n1), bias,
                         None if addend is None else _rows(addend, src.N, n0, n1),
-                        None if stats is None else stats[h], origin=origin)
+                        None if stats is None else stats[h], origin=origin, stride=stride)
 
     def dwconv_fwd(self, src: Act, w9c, stride, dil, border_mode, out, stats=None):
         if not src.split and (stats is None or stats.dim() == 3):
@@ -130,12 +130,12 @@ class DomainSplit:
                             None if residual is None else _rows(residual, src.N, n0, n1))
 
     # ------------------------------------------------------------------ backward
-    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0, stride=1):
         if not src.split:
-            return self.K.conv_wgrad(src, dy, ksize, dil, dw, origin=origin)
+            return self.K.conv_wgrad(src, dy, ksize, dil, dw, origin=origin, stride=stride)
         d1 = torch.empty_like(dw)
         for (h, n0, n1), dst in zip(self._halves(src.N), (dw, d1)):
-            self.K.conv_wgrad(src.half(h), _rows(dy, src.N, n0, n1), ksize, dil, dst, origin=origin)
+            self.K.conv_wgrad(src.half(h), _rows(dy, src.N, n0, n1), ksize, dil, dst, origin=origin, stride=stride)
         dw.add_(d1)
 
     def dwconv_wgrad(self, src: Act, dy, stride, dil, border_mode, dw):

@@ -30,6 +30,7 @@ import torch
 import os as _os
 
 _MC_VIRTUAL = _os.environ.get("UDA_CLR_MC_VIRTUAL", "1") != "0"      # A/B switch: stochastic passes without the x_feature matrix
+_NATIVE_S2 = _os.environ.get("UDA_CLR_NATIVE_STRIDE2", "1") != "0"    # A/B switch: ResNet's stride-2 3x3 convs on the strided grid (0: stride 1 + subsample)
 POISON_BUFFERS = False      # tests/test_generator_gpu.py sets it: every fp32 work matrix starts as NaN / Inf / huge values
 
 from .acts import ACT_NONE, ACT_RELU, ACT_RELU6, Act, BNRec, nchw_view, round4
@@ -391,8 +392,9 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------ ResNet-101 backbone
     def _resnet_forward(self, ctx, x, training):
-        """resnet.py:113-124.  The two stride-2 bottlenecks (layer2.0, layer3.0) run their 3x3 conv at
-        stride 1 on the MFMA kernel and keep every other pixel (4 % extra FLOPs of the backbone)."""
+        """resnet.py:113-124.  The 3x3 convs of the two stride-2 bottlenecks (layer2.0, layer3.0) and their weight gradients walk
+        the strided output grid in the wide-tile kernels' loaders; only their input gradient is a stride-1 conv of the
+        zero-stuffed gradient."""
         K, S, params = self.K, ctx.S, ctx.params
         N, _, Hin, Win = x.shape
         H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
@@ -418,8 +420,8 @@ class GeneratorEngine:
             a1 = self._bn_act(ctx, pre + ".bn1", y1, N, H, W, st, P, training, ACT_RELU)
             y2 = self._buf(x, Po, planes)
             st = self._stats(ctx, planes, training)
-            if stride == 1:
-                K.conv(a1, self._w(ctx, pre + ".conv2.weight", "ohwi"), 3, dil, y2, stats=st)
+            if stride == 1 or _NATIVE_S2:
+                K.conv(a1, self._w(ctx, pre + ".conv2.weight", "ohwi"), 3, dil, y2, stats=st, **({"stride": stride} if stride != 1 else {}))
             else:
                 yfull = self._buf(x, P, planes)
                 K.conv(a1, self._w(ctx, pre + ".conv2.weight", "ohwi"), 3, dil, yfull)
@@ -472,11 +474,14 @@ class GeneratorEngine:
             self._dgrad(ctx, pre + ".conv3.weight", dy3, N, Ho, Wo, 1, 1, dU2)
             del dy3
             dy2 = self._bn_backward(ctx, G, a2, dU2)
-            if stride != 1:
+            if _NATIVE_S2:
+                self._wgrad(ctx, G, pre + ".conv2.weight", a1, dy2, 3, dil, stride)
+            if stride != 1:                   # input gradient: stride-1 conv of the zero-stuffed gradient
                 full = self._buf(x, a1.P, a2.C)
                 K.rows_stride(dy2, N, H, W, stride, full, scatter=True)
                 dy2 = full
-            self._wgrad(ctx, G, pre + ".conv2.weight", a1, dy2, 3, dil)
+            if not _NATIVE_S2:
+                self._wgrad(ctx, G, pre + ".conv2.weight", a1, dy2, 3, dil)
             dU1 = self._buf(x, a1.P, a1.C)
             self._dgrad(ctx, pre + ".conv2.weight", dy2, N, H, W, 3, dil, dU1)
             del dU2, dy2
@@ -849,9 +854,9 @@ class GeneratorEngine:
             G[key + ".bias"] = db[sl]
         return out
 
-    def _wgrad(self, ctx, G, key, src: Act, dy, ksize, dil):
+    def _wgrad(self, ctx, G, key, src: Act, dy, ksize, dil, stride=1):
         dw = torch.empty_like(ctx.params[key])
-        self.K.conv_wgrad(src, dy, ksize, dil, dw)
+        self.K.conv_wgrad(src, dy, ksize, dil, dw, **({"stride": stride} if stride != 1 else {}))
         G[key] = dw
 
     def _dgrad(self, ctx, key, dy, N, H, W, ksize, dil, out, addend=None):

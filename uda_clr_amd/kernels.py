@@ -31,14 +31,14 @@ class UdaConvArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("w", C.c_void_p), ("Cout", C.c_int32), ("ksize", C.c_int32),
                 ("dil", C.c_int32), ("origin", C.c_int32), ("bias", C.c_void_p), ("addend", C.c_void_p),
                 ("ld_add", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("stats", C.c_void_p),
-                ("mfma", C.c_int32), ("_pad3", C.c_int32), ("x3_src", C.c_void_p), ("x3_w", C.c_void_p),
+                ("mfma", C.c_int32), ("stride", C.c_int32), ("x3_src", C.c_void_p), ("x3_w", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
 class UdaWgradArgs(C.Structure):
     _fields_ = [("src", UdaSrc), ("dy", C.c_void_p), ("lddy", C.c_int64), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("dil", C.c_int32), ("origin", C.c_int32), ("dw", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64), ("mfma", C.c_int32), ("_pad3", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64), ("mfma", C.c_int32), ("stride", C.c_int32),
                 ("x3_src", C.c_void_p), ("x3_dy", C.c_void_p)]
 
 
@@ -260,15 +260,17 @@ class HipKernels:
         r = slice(n0 * ppi, n1 * ppi)
         return Act(a.x[r], n1 - n0, a.H, a.W, a.scale, a.shift, a.act, None if a.mask is None else a.mask[r], a.mask_scale, a.bn, a.meta)
 
-    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0):
+    def conv(self, src: Act, w, ksize, dil, out, bias=None, addend=None, stats=None, origin=0, stride=1):
+        """stride 2 (wide tiles only: the C side raises otherwise): ``out`` / ``addend`` / ``stats`` live on the strided grid"""
         groups = self._image_groups(src.N, src.P // src.N, max(src.x.stride(0), out.stride(0), 0 if addend is None else addend.stride(0),
                                                                0 if src.mask is None else src.mask.stride(0) // 4),
                                     src.C if self.mfma != self.MFMA_F32 else 0)
+        Po = src.N * ((src.H - 1) // stride + 1) * ((src.W - 1) // stride + 1)
         if groups is not None:
-            ppi = src.P // src.N
+            ppo = Po // src.N
             for n0, n1 in groups:
-                r = slice(n0 * ppi, n1 * ppi)
-                self.conv(self._act_rows(src, n0, n1), w, ksize, dil, out[r], bias, None if addend is None else addend[r], stats, origin)
+                r = slice(n0 * ppo, n1 * ppo)
+                self.conv(self._act_rows(src, n0, n1), w, ksize, dil, out[r], bias, None if addend is None else addend[r], stats, origin, stride)
             return
         a = UdaConvArgs()
         a.origin = origin
@@ -276,8 +278,8 @@ class HipKernels:
         Cout = out.shape[1]
         assert w.is_contiguous() and tuple(w.shape) == conv_weight_shape(Cout, ksize, src.C), \
             "weight layout %s does not match conv %dx%d %d->%d" % (tuple(w.shape), ksize, ksize, src.C, Cout)
-        assert out.shape[0] == src.P
-        a.w, a.Cout, a.ksize, a.dil = w.data_ptr(), Cout, ksize, dil
+        assert out.shape[0] == Po and stride in (1, 2)
+        a.w, a.Cout, a.ksize, a.dil, a.stride = w.data_ptr(), Cout, ksize, dil, stride
         a.bias = _ptr(bias)
         if bias is not None:
             assert bias.is_contiguous() and bias.numel() == Cout
@@ -349,13 +351,16 @@ class HipKernels:
         s.act, s.ldm, s.mask_scale = 0, 0, 1.0
         return self.x3_pack(s, rows, klen, w.device)
 
-    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0):
+    def conv_wgrad(self, src: Act, dy, ksize, dil, dw, origin=0, stride=1):
+        """stride 2 (wide tiles only): ``dy`` lives on the strided output grid of the forward conv"""
         groups = self._image_groups(src.N, src.P // src.N, max(src.x.stride(0), dy.stride(0), 0 if src.mask is None else src.mask.stride(0) // 4))
+        Ho, Wo = (src.H - 1) // stride + 1, (src.W - 1) // stride + 1
+        Po = src.N * Ho * Wo
         if groups is not None:
-            ppi = src.P // src.N
+            ppo = Po // src.N
             tmp = torch.empty_like(dw)
             for i, (n0, n1) in enumerate(groups):
-                self.conv_wgrad(self._act_rows(src, n0, n1), dy[n0 * ppi:n1 * ppi], ksize, dil, dw if i == 0 else tmp, origin)
+                self.conv_wgrad(self._act_rows(src, n0, n1), dy[n0 * ppo:n1 * ppo], ksize, dil, dw if i == 0 else tmp, origin, stride)
                 if i:
                     dw.add_(tmp)
             return
@@ -363,18 +368,18 @@ class HipKernels:
         a.origin = origin
         a.src = self._src(src)
         Cout = dy.shape[1]
-        assert dy.shape[0] == src.P and dw.is_contiguous() and tuple(dw.shape) == (Cout, src.C, ksize, ksize)
+        assert dy.shape[0] == Po and stride in (1, 2) and dw.is_contiguous() and tuple(dw.shape) == (Cout, src.C, ksize, ksize)
         a.dy, a.lddy = _mat(dy, "dy")
-        a.Cout, a.ksize, a.dil = Cout, ksize, dil
+        a.Cout, a.ksize, a.dil, a.stride = Cout, ksize, dil, stride
         a.dw = dw.data_ptr()
-        ws = self._ws(dy, self.lib.uda_conv_wgrad_workspace_bytes(src.P, Cout, src.C, ksize))
+        ws = self._ws(dy, self.lib.uda_conv_wgrad_workspace_bytes(Po, Cout, src.C, ksize))
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.mfma = self.mfma
         if self.mfma != self.MFMA_F32 and self.lib.uda_conv_wgrad_uses_x3(C.byref(a)):
             # bf16x3: the source's packed form usually exists already (the forward conv packed the same descriptor); dy is packed
             # once for its input-gradient conv and this weight gradient (the packed form rides on the tensor object)
             xs = self._packed(src, a.src, dy.device)
-            dsrc = Act(dy, src.N, src.H, src.W)
+            dsrc = Act(dy, src.N, Ho, Wo)
             xd = self._packed(dsrc, self._src(dsrc), dy.device)
             a.x3_src, a.x3_dy = xs.data_ptr(), xd.data_ptr()
         self._ck(self.lib.uda_conv_wgrad(C.byref(a), self._stream()))

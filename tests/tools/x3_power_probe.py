@@ -18,11 +18,15 @@ for p in (os.path.dirname(os.path.dirname(HERE)), os.path.dirname(HERE)):
 import torch
 
 from uda_clr_amd.acts import Act
+import uda_clr_amd.kernels as _kmod
 from uda_clr_amd.kernels import HipKernels
+
+if os.environ.get("UDA_PROBE_LIB"):          # A/B of two builds of the library on one box (this tool only)
+    _kmod._LIB_PATH = os.path.abspath(os.environ["UDA_PROBE_LIB"])
 
 dev = torch.device("cuda:0")
 K = HipKernels(mfma="bf16x3")
-out_f = open(os.path.join("gpurun_out", "x3_power_probe.txt"), "w") if os.path.isdir("gpurun_out") else None
+out_f = open(os.path.join("gpurun_out", "x3_power_probe.txt"), "a") if os.path.isdir("gpurun_out") else None
 
 
 def emit(s):
@@ -37,7 +41,9 @@ def run(N, fill):
     Cin = Cout = 256
     P = N * H * W
     g = torch.Generator(device=dev).manual_seed(1)
-    x = torch.randn(P, Cin, generator=g, device=dev) if fill == "random" else torch.zeros(P, Cin, device=dev)
+    x = torch.randn(P, Cin, generator=g, device=dev) if fill != "zero-x" and fill != "zero-all" else torch.zeros(P, Cin, device=dev)
+    if fill == "sparse75":                  # what conv4 reads inside the step: ReLU then dropout 0.5 leave ~25 % non-zeros
+        x = x * (torch.rand(P, Cin, generator=g, device=dev) < 0.25)
     w = torch.randn(Cout, Cin, 3, 3, generator=g, device=dev) / 48.0 if fill != "zero-all" else torch.zeros(Cout, Cin, 3, 3, device=dev)
     wl = K.relayout_ohwi(w)
     out = torch.empty(P, Cout, device=dev)
@@ -78,5 +84,5 @@ def run(N, fill):
 
 emit("bf16x3 conv4 (3x3 256->256 @128^2, 256x256 tiles): matrix-pipe floor = tiles/256 x 144 chunks x 3072 cycles")
 for N in (16, 32):
-    for fill in ("random", "zero-x", "zero-all"):
+    for fill in ("random", "sparse75", "zero-x", "zero-all"):
         run(N, fill)

@@ -17,6 +17,7 @@
 //                    deterministic, no float atomics)
 //
 // Both are bound by cache / HBM bandwidth (the strip kernel: 13.5 cached 16-byte reads per 16-byte output at x4).
+#include <algorithm>
 #include "common.h"
 #include "bilinear.h"
 
@@ -186,6 +187,184 @@ __global__ __launch_bounds__(256) void upconv_fwd_strip_kernel(const float* __re
     (void)cg_mine;
 }
 
+// Tile variant (x4-like upsampling, the decoder's shape): one workgroup computes a 16 x 16 output tile of 32 channels.
+//   * The low-resolution footprint of the tile - every g pixel one of its tap positions blends, at most R x RC pixels x 9 taps - is
+//     fetched ONCE into LDS with back-to-back 16-byte loads; the blends read it from there.
+//   * The strip kernel turned out to be bound by its VECTOR ARITHMETIC, not by its cached reads: ~1.4 k vector instructions per
+//     strip (index / weight arithmetic of 15 bil_src per strip and 72 multiply-adds per tap), 4 cycles each on a wave64 - 170 of its
+//     300 us at 16 images.  Here the interpolation weights are tabulated once per workgroup (18 tap rows, 4 strip columns x 3
+//     horizontal taps), the three vertical taps are summed BEFORE the horizontal blend
+//         V[tw][c] = sum_th lh0(th) * g_{th,tw}[h0(th)][a + c] + lh1(th) * g_{th,tw}[h1(th)][a + c],   y[j] += cw[tw][j][c] * V[tw][c]
+//     (90 instead of 162 four-channel multiply-adds per strip), on packed pairs (v_pk_fma_f32).
+//   Same sums as the strip kernel in another association: results agree to fp32 rounding, not bit for bit.
+#define UPT_TH 16
+#define UPT_TW 16
+#define UPT_CS 32            // channels per workgroup (8 granules of 4)
+__global__ __launch_bounds__(256) void upconv_fwd_tile_kernel(const float* __restrict__ g, int64_t ldg, int N, int h, int w, int C,
+                                                              const float* __restrict__ addend, int64_t ld_add, int64_t add_rows,
+                                                              float* __restrict__ y, int64_t ldy, int H, int W, float sh, float sw,
+                                                              double* __restrict__ stats, int R, int RC) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float4 foot[];            // [R][RC][9 taps][8 granules]
+    __shared__ float red[2][256][4];
+    __shared__ float4 rowtab[UPT_TH + 2];        // tap row yy = oh0 - 1 + i: (footprint row of h0) * RC, (.. of h1) * RC [as ints], lh0, lh1 (0, 0 outside the image)
+    __shared__ float coltab[4][3][16];           // strip column sc, horizontal tap tw: 3 footprint columns [as ints], then cw[4 pixels][3 columns]
+    constexpr int NC = 3, dil = 1;
+    const int tid = threadIdx.x;
+    const int nCs = C / UPT_CS, nTx = W / UPT_TW, nTy = H / UPT_TH;
+    // consecutive workgroups: the channel slices of one tile (adjacent 128-byte segments of the same output rows), then the tiles of
+    // a row of tiles; each XCD keeps a contiguous range
+    int b = uda_xcd_remap(blockIdx.x, gridDim.x);
+    const int cs = b % nCs;
+    b /= nCs;
+    const int tx = b % nTx;
+    b /= nTx;
+    const int ty = b % nTy, n = b / nTy;
+    const int oh0 = ty * UPT_TH, ow0t = tx * UPT_TW;
+    // footprint origin: the first low-resolution row / column the tile's topmost / leftmost tap position reads
+    int hlo, wlo, i1;
+    float t0, t1;
+    bil_src(max(oh0 - dil, 0), sh, h, hlo, i1, t0, t1);
+    bil_src(max(ow0t - dil, 0), sw, w, wlo, i1, t0, t1);
+    {
+        const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)((int64_t)N * h * w * ldg * 4), 0x00020000);
+        const int ldg4 = (int)ldg * 4, nload = R * RC * 72;
+        const int base = ((n * h) * w) * ldg4 + (cs * UPT_CS) * 4;
+        for (int i = tid; i < nload; i += 256) {
+            const int cg = i & 7, q = i >> 3, pc = q / 9, tap = q - pc * 9, r = pc / RC, c = pc - r * RC;
+            const int hh = min(hlo + r, h - 1), ww = min(wlo + c, w - 1);            // (rows / columns beyond the image: never blended)
+            foot[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gres, base + (hh * w + ww) * ldg4 + cg * 16, tap * C * 4, 0));
+        }
+    }
+    if (tid < UPT_TH + 2) {                      // row table
+        const int yy = oh0 - dil + tid;
+        int h0 = hlo, h1 = hlo;
+        float lh0 = 0.f, lh1 = 0.f;
+        if (yy >= 0 && yy < H) bil_src(yy, sh, h, h0, h1, lh0, lh1);
+        rowtab[tid] = make_float4(__int_as_float((h0 - hlo) * RC), __int_as_float((h1 - hlo) * RC), lh0, lh1);
+    } else if (tid >= 64 && tid < 64 + 12) {     // column tables (as the strip kernel's column part)
+        const int sc = (tid - 64) / 3, tw = (tid - 64) % 3;
+        const int xb = ow0t + sc * 4 + (tw - 1) * dil;
+        int acol, a1;
+        bil_src(max(xb, 0), sw, w, acol, a1, t0, t1);
+        float* ct = coltab[sc][tw];
+        // footprint column of low-resolution column a + c, clamped into the loaded range (its weight is 0 beyond: finite data, no NaN)
+        for (int c = 0; c < NC; ++c) ct[c] = __int_as_float(max(min(min(acol + c, w - 1) - wlo, RC - 1), 0));
+        for (int jx = 0; jx < 4; ++jx) {
+            const int xx = xb + jx;
+            int w0, w1;
+            float lw0, lw1;
+            bil_src(min(max(xx, 0), W - 1), sw, w, w0, w1, lw0, lw1);
+            const bool in = xx >= 0 && xx < W;
+            const int i0 = w0 - acol, i1c = w1 - acol;
+            for (int c = 0; c < NC; ++c) ct[3 + jx * 3 + c] = in ? (i0 == c ? lw0 : 0.f) + (i1c == c ? lw1 : 0.f) : 0.f;
+        }
+    }
+    // the addend rows of this thread's first strip travel with the footprint loads, those of its second strip under the first's blends
+    const int cg = tid & 7, s = tid >> 3, sc = s & 3, ow0 = ow0t + sc * 4, srow = s >> 2;
+    const unsigned arows = (unsigned)add_rows;
+    const int lda32 = (int)ld_add, ch = cs * UPT_CS + cg * 4;
+    float4 ad[2][4];
+    auto load_addend = [&](int k) {
+        const unsigned p0 = ((unsigned)n * (unsigned)H + (unsigned)(oh0 + srow + 8 * k)) * (unsigned)W + (unsigned)ow0;
+        unsigned ar = addend ? p0 % arows : 0u;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            ad[k][jx] = addend ? uda_ld4(addend + (int64_t)ar * lda32 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (++ar >= arows) ar = 0u;
+        }
+    };
+    load_addend(0);
+    __syncthreads();
+    load_addend(1);
+    int lc[3][NC];
+    float cw[3][4][NC];
+#pragma unroll
+    for (int tw = 0; tw < 3; ++tw) {
+        const float* ct = coltab[sc][tw];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) lc[tw][c] = __float_as_int(ct[c]) * 72 + cg;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cw[tw][jx][c] = ct[3 + jx * 3 + c];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int row = srow + 8 * k, oh = oh0 + row;
+        const unsigned p0 = ((unsigned)n * (unsigned)H + (unsigned)oh) * (unsigned)W + (unsigned)ow0;
+        f32x2 acc[4][2];
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            acc[jx][0] = f32x2{ad[k][jx].x, ad[k][jx].y};
+            acc[jx][1] = f32x2{ad[k][jx].z, ad[k][jx].w};
+        }
+        int r0[3], r1[3];
+        float lh0[3], lh1[3];
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const float4 rt = rowtab[row + th];
+            r0[th] = __float_as_int(rt.x) * 72 + th * 24;        // + tap * 8 with tap = th * 3 + tw
+            r1[th] = __float_as_int(rt.y) * 72 + th * 24;
+            lh0[th] = rt.z;
+            lh1[th] = rt.w;
+        }
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+#pragma unroll
+                for (int th = 0; th < 3; ++th) {
+                    const float4 a0 = foot[r0[th] + lc[tw][c] + tw * 8], a1v = foot[r1[th] + lc[tw][c] + tw * 8];
+                    v0 += f32x2{a0.x, a0.y} * lh0[th];
+                    v0 += f32x2{a1v.x, a1v.y} * lh1[th];
+                    v1 += f32x2{a0.z, a0.w} * lh0[th];
+                    v1 += f32x2{a1v.z, a1v.w} * lh1[th];
+                }
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    acc[jx][0] += v0 * cw[tw][jx][c];
+                    acc[jx][1] += v1 * cw[tw][jx][c];
+                }
+            }
+        }
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float4 o = make_float4(acc[jx][0].x, acc[jx][0].y, acc[jx][1].x, acc[jx][1].y);
+            uda_st4(y + (int64_t)(p0 + jx) * ldy + ch, o);
+            s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
+            s2[0] += o.x * o.x; s2[1] += o.y * o.y; s2[2] += o.z * o.z; s2[3] += o.w * o.w;
+        }
+    }
+    if (stats) {            // thread t owns granule t & 7 of this workgroup's 32 channels
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            red[0][tid][jx] = s1[jx];
+            red[1][tid][jx] = s2[jx];
+        }
+        __syncthreads();
+        if (tid < 2 * UPT_CS) {
+            const int qd = tid / UPT_CS, c = tid % UPT_CS, cgc = c >> 2, jx = c & 3;
+            float t = 0.f;
+            for (int k = cgc; k < 256; k += 8) t += red[qd][k][jx];
+            double* dst = stats + (int64_t)(blockIdx.x % UDA_STAT_SLOTS) * 2 * C;
+            atomicAdd(&dst[qd * C + cs * UPT_CS + c], (double)t);
+        }
+    }
+}
+
+// rows (columns) of the low-resolution footprint of a tile whose tap positions span [o_min, o_max] (clipped to the image)
+static int upconv_foot(int o_min, int o_max, float scale, int n_in, int n_out) {
+    const float lo = scale * (float)(o_min < 0 ? 0 : o_min), hi = scale * (float)(o_max > n_out - 1 ? n_out - 1 : o_max);
+    int i_lo = (int)lo, i_hi = (int)hi;
+    if (i_lo > n_in - 1) i_lo = n_in - 1;
+    if (i_hi > n_in - 1) i_hi = n_in - 1;
+    i_hi += i_hi < n_in - 1 ? 1 : 0;
+    return i_hi - i_lo + 1;
+}
+
 static bool upconv_strip_ok(int w, int W, int C, int dil, int H = 4) {
     if (H % 4) return false;
     // the four tap positions of a strip span 3*sw low-resolution columns: floor(frac + 3*sw) + 1 <= NC - 1 with NC <= 4
@@ -213,6 +392,21 @@ extern "C" int uda_upconv_fwd(const float* g, int64_t ldg, int N, int h, int w, 
     const int64_t lim32 = (int64_t)1 << 31;          // the strip kernel indexes in 32 bits
     if (upconv_strip_ok(w, W, C, dil, H) && (int64_t)N * H * W < lim32 && (int64_t)N * H * (W / 4) * G < lim32 - 65536 * 256 &&
         (int64_t)N * h * w * ldg * 4 < lim32 && (!addend || addend_rows * ld_add < lim32 * 4)) {
+        // the LDS-tiled kernel where the tiling fits (x4-like upsampling of a map whose sides are multiples of 16)
+        static const int tile_env = getenv("UDA_UPCONV_TILE") ? atoi(getenv("UDA_UPCONV_TILE")) : 1;      // A/B switch
+        if (tile_env && 3.f * sw < 0.98f && H % UPT_TH == 0 && W % UPT_TW == 0 && C % UPT_CS == 0) {
+            int R = 1, RC = 1;
+            for (int ty = 0; ty < H / UPT_TH; ++ty) R = std::max(R, upconv_foot(ty * UPT_TH - 1, ty * UPT_TH + UPT_TH, sh, h, H));
+            for (int tx = 0; tx < W / UPT_TW; ++tx) RC = std::max(RC, upconv_foot(tx * UPT_TW - 1, tx * UPT_TW + UPT_TW, sw, w, W));
+            const size_t lds = (size_t)R * RC * 72 * sizeof(float4);
+            const int64_t nwg = (int64_t)N * (H / UPT_TH) * (W / UPT_TW) * (C / UPT_CS);
+            if (lds <= 64 * 1024 - 8192 && nwg < lim32) {
+                hipLaunchKernelGGL(upconv_fwd_tile_kernel, dim3((unsigned)nwg), dim3(256), lds, st, g, ldg, N, h, w, C, addend, ld_add,
+                                   addend ? addend_rows : 1, y, ldy, H, W, sh, sw, stats, R, RC);
+                UDA_LAUNCH_CHECK("upconv_fwd_tile");
+                return 0;
+            }
+        }
         const int64_t total = (int64_t)N * H * (W / 4) * G;
         int grid = uda_cdiv(total, 256);
         if (grid > 4096) grid = 4096;           // bounded: the statistics epilogue issues 2*C atomics per workgroup

@@ -569,6 +569,9 @@ CASES = [
     ("upsample + stats 8x8->32x32 C=256 into 305 (+ 49-channel window)", case_upsample_stats(2, 8, 8, 32, 32, 256, 305)),
     ("mc seg head 4 x (8x8 -> 32x32) 256 + 48 + 1, batch repeated twice, mask", case_mc_seg_head(4, 8, 8, 32, 32, 256, 48, 2, True)),
     ("mc seg head 3 x (5x7 -> 20x28) 64 + 8 + 1, no repeat, no mask", case_mc_seg_head(3, 5, 7, 20, 28, 64, 8, 1, False)),
+    ("mc seg head 2 x (5x9 -> 17x33) exact ratio 1/4 (last source row / column reached exactly)", case_mc_seg_head(2, 5, 9, 17, 33, 64, 8, 1, False)),
+    ("mc seg head 2 x (6x6 -> 6x6) ratio 1, (3x4 -> 13x7) mixed", case_mc_seg_head(2, 6, 6, 6, 6, 64, 8, 1, True)),
+    ("mc seg head 2 x (3x4 -> 13x7) 64 + 8 + 1", case_mc_seg_head(2, 3, 4, 13, 7, 64, 8, 1, False)),
     ("bn backward, low-rank dU: C=305 k=2 mask (seg head)", case_bnbwd_lowrank(3000, 305, 2, True)),
     ("bn backward, low-rank dU: C=256 k=1 mask (boundary head)", case_bnbwd_lowrank(2500, 256, 1, True)),
     ("bn backward, low-rank dU: C=40 k=2 raw", case_bnbwd_lowrank(777, 40, 2, False)),
@@ -1158,6 +1161,10 @@ CASES += [
     ("upconv fwd/bwd 1 x (85x85 -> 128x128) x 8 (scale 0.661: 4-column strips)", case_upconv(1, 85, 85, 128, 128, 8)),
     ("upconv fwd/bwd 1 x (86x86 -> 128x128) x 8 (scale 0.669: pixel kernel)", case_upconv(1, 86, 86, 128, 128, 8)),
     ("upconv fwd/bwd 3 x (32x32 -> 128x128) x 256 (the decoder's shape)", case_upconv(3, 32, 32, 128, 128, 256, addend_rows=16384)),
+    ("upconv fwd/bwd 2 x (4x4 -> 16x16) x 256 (tile kernel, one tile; wave-per-pixel bwd)", case_upconv(2, 4, 4, 16, 16, 256, addend_rows=256)),
+    ("upconv fwd/bwd 1 x (5x9 -> 17x33) x 256 (exact ratio 1/4, odd sizes: strip / pixel fwd, wave bwd)", case_upconv(1, 5, 9, 17, 33, 256)),
+    ("upconv fwd/bwd 1 x (9x5 -> 32x16) x 256 (tile kernel, ratio 0.258 / 0.267), addend", case_upconv(1, 9, 5, 32, 16, 256, addend_rows=512)),
+    ("upconv fwd/bwd 2 x (16x16 -> 48x64) x 256 (tile kernel at x3 / x4.2)", case_upconv(2, 16, 16, 48, 64, 256)),
     ("upconv identity vs interpolate+conv2d 2 x (8x8 -> 32x32), 64+16 -> 32", case_upconv_identity(2, 8, 8, 32, 32, 64, 16, 32)),
 ]
 

@@ -481,6 +481,66 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const float* __restrict
     }
 }
 
+// Wave-per-pixel variant (C = 256: the 64 lanes of a wave are the 64 channel granules of ONE low-resolution pixel).  The thread-per-
+// (pixel, granule) kernel above is bound by its vector arithmetic: every lane re-derives the same interpolation weights (a bil_src
+// per (row, tap) and per (row, column, tap)) and spends 36 multiply-adds per dy value.  Here
+//   * the weights are wave-uniform: lane l < 32 evaluates the row weight A(hlo + l) = weight of tap ROW position hlo + l on source row ih,
+//     lane 32 + l the column weight B(wlo + l), once; the loops fetch them with v_readlane into scalar registers;
+//   * the column sums are formed first, tmp[tw] = sum_ow B(ow + tw - 1) dy[oh][ow] (12 multiply-adds per dy value), then
+//     dG[(th, tw)] += A(oh + th - 1) tmp[tw] once per row.
+__global__ __launch_bounds__(256) void upconv_bwd_wave_kernel(const float* __restrict__ dy, int64_t ldy, int N, int H, int W, int C,
+                                                              float* __restrict__ dg, int64_t ldg, int h, int w, float sh, float sw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t npix = (int64_t)N * h * w;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t qv = wave0; qv < npix; qv += nwaves) {
+        const int64_t q = __builtin_amdgcn_readfirstlane((int)qv);          // (npix < 2^31, host-checked)
+        const int iw = (int)(q % w), ih = (int)((q / w) % h), n = (int)(q / ((int64_t)w * h));
+        int hlo, hhi, wlo, whi;
+        bil_range(ih, sh, H, hlo, hhi);         // tap positions (inside the image) that can read low-resolution row ih / column iw
+        bil_range(iw, sw, W, wlo, whi);
+        // (host-checked: both ranges are at most 32 wide)
+        const int l31 = lane & 31;
+        const float tab = lane < 32 ? (hlo + l31 <= hhi ? bil_weight(hlo + l31, sh, h, ih) : 0.f)
+                                    : (wlo + l31 <= whi ? bil_weight(wlo + l31, sw, w, iw) : 0.f);
+        auto A = [&](int yy) { return (yy >= hlo && yy <= hhi) ? __builtin_amdgcn_readlane(__float_as_int(tab), yy - hlo) : 0; };
+        auto B = [&](int xx) { return (xx >= wlo && xx <= whi) ? __builtin_amdgcn_readlane(__float_as_int(tab), 32 + xx - wlo) : 0; };
+        float4 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int oh0 = max(hlo - 1, 0), oh1 = min(hhi + 1, H - 1), ow0 = max(wlo - 1, 0), ow1 = min(whi + 1, W - 1);
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            const float a0 = __int_as_float(A(oh - 1)), a1 = __int_as_float(A(oh)), a2 = __int_as_float(A(oh + 1));
+            if (a0 == 0.f && a1 == 0.f && a2 == 0.f) continue;
+            const float* row = dy + (((int64_t)n * H + oh) * W) * ldy + lane * 4;
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0;
+            float bm = __int_as_float(B(ow0 - 1)), bc = __int_as_float(B(ow0));
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const float bp = __int_as_float(B(ow + 1));
+                const float4 v = uda_ld4(row + (int64_t)ow * ldy);
+                t0.x += bm * v.x; t0.y += bm * v.y; t0.z += bm * v.z; t0.w += bm * v.w;      // tap tw = 0 sits at ow - 1
+                t1.x += bc * v.x; t1.y += bc * v.y; t1.z += bc * v.z; t1.w += bc * v.w;
+                t2.x += bp * v.x; t2.y += bp * v.y; t2.z += bp * v.z; t2.w += bp * v.w;
+                bm = bc;
+                bc = bp;
+            }
+            const float a3[3] = {a0, a1, a2};
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                float4& r0 = acc[th * 3 + 0];
+                float4& r1 = acc[th * 3 + 1];
+                float4& r2 = acc[th * 3 + 2];
+                const float k = a3[th];
+                r0.x += k * t0.x; r0.y += k * t0.y; r0.z += k * t0.z; r0.w += k * t0.w;
+                r1.x += k * t1.x; r1.y += k * t1.y; r1.z += k * t1.z; r1.w += k * t1.w;
+                r2.x += k * t2.x; r2.y += k * t2.y; r2.z += k * t2.z; r2.w += k * t2.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) uda_st4(dg + q * ldg + t * C + lane * 4, acc[t]);
+    }
+}
+
 extern "C" int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W, int C, int dil, float* dg, int64_t ldg, int h,
                               int w, void* stream) {
     UDA_REQUIRE(dy && dg && uda_aligned16(dy) && uda_aligned16(dg) && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 &&
@@ -489,8 +549,19 @@ extern "C" int uda_upconv_bwd(const float* dy, int64_t ldy, int N, int H, int W,
     const int64_t total = (int64_t)N * h * w * (C / 4);
     int grid = uda_cdiv(total, 256);
     if (grid > 65536) grid = 65536;
+    const float sh = bil_scale(h, H), sw = bil_scale(w, W);
+    // one wave per low-resolution pixel when its 64 lanes are exactly the channel granules and the tap ranges fit the 32-entry weight tables
+    static const int wave_env = getenv("UDA_UPCONV_BWD_WAVE") ? atoi(getenv("UDA_UPCONV_BWD_WAVE")) : 1;      // A/B switch
+    if (wave_env && C == 256 && dil == 1 && sh > 0.f && sw > 0.f && 2.f / sh + 6.f <= 32.f && 2.f / sw + 6.f <= 32.f && (int64_t)N * h * w < ((int64_t)1 << 31)) {
+        const int64_t npix = (int64_t)N * h * w;
+        int gw = (int)uda_cdiv(npix, 4);
+        if (gw > 65536) gw = 65536;
+        hipLaunchKernelGGL(upconv_bwd_wave_kernel, dim3(gw), dim3(256), 0, (hipStream_t)stream, dy, ldy, N, H, W, C, dg, ldg, h, w, sh, sw);
+        UDA_LAUNCH_CHECK("upconv_bwd_wave");
+        return 0;
+    }
     hipLaunchKernelGGL(upconv_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, ldy, N, H, W, C, dil, dg, ldg, h, w,
-                       bil_scale(h, H), bil_scale(w, W));
+                       sh, sw);
     UDA_LAUNCH_CHECK("upconv_bwd");
     return 0;
 }

@@ -764,16 +764,19 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
         }
 }
 
-// dw[co][ci][t] = sum_s slab[s][co][t*Kc + ci].  32 outputs x 8 split-lanes per workgroup: lane q sums the
-// slabs s = q, q+8, ... (4 loads in flight), the 8 partial sums meet in LDS in a fixed order (bitwise
-// reproducible).  The serial one-thread-per-output form took 38 us on the small layers (S up to 256).
+// dw[co][ci][t] = sum_s slab[s][co][t*Kc + ci].  256 / Q outputs x Q split-lanes per workgroup: lane q sums the
+// slabs s = q, q+Q, ... (4 loads in flight), the Q partial sums meet in LDS in a fixed order (bitwise
+// reproducible).  Q = 8 (32 outputs per workgroup); Q = 64 for the many-slab plans of tiny weights (S up to 1024).
+// The serial one-thread-per-output form took 38 us on the small layers (S up to 256).
+template <int Q>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int S, int Cout, int Cin, int T,
                                                            int Kc, float* __restrict__ dw) {
-    __shared__ float red[8][33];
+    constexpr int NO = 256 / Q;
+    __shared__ float red[Q][NO + 1];
     const int64_t total = (int64_t)Cout * T * Cin;
     const int64_t stride = (int64_t)Cout * T * Kc;
-    const int ol = threadIdx.x & 31, q = threadIdx.x >> 5;
-    for (int64_t e0 = (int64_t)blockIdx.x * 32; e0 < total; e0 += (int64_t)gridDim.x * 32) {
+    const int ol = threadIdx.x % NO, q = threadIdx.x / NO;
+    for (int64_t e0 = (int64_t)blockIdx.x * NO; e0 < total; e0 += (int64_t)gridDim.x * NO) {
         const int64_t e = e0 + ol;
         float s = 0.f;
         int64_t dst = 0;
@@ -785,19 +788,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             const float* src = slab + ((int64_t)co * T + t) * Kc + ci;
             int k = q;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (; k + 24 < S; k += 32) {
+            for (; k + 3 * Q < S; k += 4 * Q) {
                 s0 += src[(int64_t)k * stride];
-                s1 += src[(int64_t)(k + 8) * stride];
-                s2 += src[(int64_t)(k + 16) * stride];
-                s3 += src[(int64_t)(k + 24) * stride];
+                s1 += src[(int64_t)(k + Q) * stride];
+                s2 += src[(int64_t)(k + 2 * Q) * stride];
+                s3 += src[(int64_t)(k + 3 * Q) * stride];
             }
-            for (; k < S; k += 8) s0 += src[(int64_t)k * stride];
+            for (; k < S; k += Q) s0 += src[(int64_t)k * stride];
             s = (s0 + s1) + (s2 + s3);
         }
         red[q][ol] = s;
         __syncthreads();
-        if (q == 0 && e < total)
-            dw[dst] = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
+        if (q == 0 && e < total) {
+            float acc[8];           // eight interleaved partial sums, combined as a tree: the same association for every Q
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) acc[j & 7] += red[j][ol];
+            dw[dst] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
         __syncthreads();
     }
 }
@@ -823,7 +832,10 @@ static WgradPlan wgrad_plan(int64_t P, int Cout, int Cin, int ksize) {
     int S = (p.bm == 256 ? 512 : 1024) / (p.nCot * p.nJt);      // 256 x 256 tiles: one workgroup per CU, two rounds
     if (S > p.nchunks / 4) S = p.nchunks / 4;
     if (S < 1) S = 1;
-    if (S > 256) S = 256;
+    // up to 256 slabs; up to 1024 for a tiny weight (one or two tiles over a million pixels: the backbone's first blocks, the decoder's
+    // 24 -> 48 conv): with 256 workgroups each walks thousands of pixels at one chunk's load latency per chunk, and its slabs are small
+    const int scap = (int64_t)Cout * J <= 8192 ? 1024 : 256;
+    if (S > scap) S = scap;
     p.cps = uda_cdiv(p.nchunks, S);
     p.S = uda_cdiv(p.nchunks, p.cps);
     return p;
@@ -889,8 +901,12 @@ extern "C" int uda_conv_wgrad(const uda_wgrad_args_t* a, void* stream) {
     UDA_LAUNCH_CHECK("igemm_wgrad");
     const int T = a->ksize * a->ksize;
     const int64_t total = (int64_t)a->Cout * T * a->src.C;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(uda_cdiv(total, 32) > 4096 ? 4096 : uda_cdiv(total, 32)), dim3(256), 0, st,
-                       k.slab, S_used, a->Cout, a->src.C, T, k.Kc, a->dw);
+    if (S_used > 256)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(uda_cdiv(total, 4) > 4096 ? 4096 : uda_cdiv(total, 4)), dim3(256), 0, st,
+                           k.slab, S_used, a->Cout, a->src.C, T, k.Kc, a->dw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(uda_cdiv(total, 32) > 4096 ? 4096 : uda_cdiv(total, 32)), dim3(256), 0, st,
+                           k.slab, S_used, a->Cout, a->src.C, T, k.Kc, a->dw);
     UDA_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }

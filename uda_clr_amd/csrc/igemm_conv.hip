@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int TILE = (BM + BN) * IG_LD;
-    __shared__ __attribute__((aligned(16))) float smem[(PIPE ? 2 : 1) * TILE];
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // (PIPE ? 2 : 1) * TILE floats (launch_conv)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -492,12 +492,26 @@ template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(BM == 128 || BM == 64, "tiles of 128 or 64 pixels");
+    constexpr size_t tile_bytes = (size_t)(BM + BN) * IG_LD * sizeof(float);
+    static_assert(2 * tile_bytes <= 160 * 1024, "two tile images must fit the LDS");
     k.nMt = uda_cdiv(P, BM);
     k.nNt = uda_cdiv(k.Cout, BN);
     // long K: the pipelined form (two tile images, loads two chunks ahead); short K keeps the lean one (more workgroups per CU)
     static const int pipe_min = getenv("UDA_CONV_PIPE_MIN_K") ? atoi(getenv("UDA_CONV_PIPE_MIN_K")) : 192;
-    if (k.Ktot >= pipe_min) hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN, true>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN, false>), dim3(k.nMt * k.nNt), dim3(256), 0, st, k);
+    if (k.Ktot >= pipe_min) {
+        auto fn = igemm_conv_kernel<TM, TN, WM, WN, true>;
+        if (2 * tile_bytes > 64 * 1024) {                   // beyond the default dynamic-LDS limit: raise it once per device
+            static bool configured_dev[UDA_MAX_DEVICES] = {};
+            bool& configured = configured_dev[uda_device_slot()];
+            if (!configured) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile_bytes));
+                if (e != hipSuccess) return uda_set_error("igemm_conv: cannot reserve %zu B of LDS: %s", 2 * tile_bytes, hipGetErrorString(e));
+                configured = true;
+            }
+        }
+        hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3(256), 2 * tile_bytes, st, k);
+    }
+    else hipLaunchKernelGGL((igemm_conv_kernel<TM, TN, WM, WN, false>), dim3(k.nMt * k.nNt), dim3(256), tile_bytes, st, k);
     UDA_LAUNCH_CHECK("igemm_conv");
     return 0;
 }
@@ -587,7 +601,21 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     // few pixels (the 32x32-map layers at B = 16: 128 tiles of 128 pixels for 256 CUs): 64-pixel tiles, twice the workgroups
     static const int low_env = getenv("UDA_CONV_LOW") ? atoi(getenv("UDA_CONV_LOW")) : 1;
     const bool low = low_env && P > 64 && uda_cdiv(P, 128) * uda_cdiv(a->Cout, a->Cout <= 64 ? 64 : 128) <= 192;
+    // few pixels, wide output, long K (the project convs of the 32x32-map layers: 960 -> 160, 576 -> 160, 960 -> 320 at P = 16384): the
+    // 128 x 128 wide tiles pad 160 columns to 256 and give one workgroup per CU; 64-pixel tiles of 192 or 320 columns give the same 256
+    // workgroups with 17 % / no padding
+    static const int few_env = getenv("UDA_CONV_FEW") ? atoi(getenv("UDA_CONV_FEW")) : 1;
+    int few_w = 0;
+    if (few_env && P > 64 && uda_cdiv(P, 128) <= 192) {
+        const int c192 = uda_cdiv(a->Cout, 192) * 192, c320 = uda_cdiv(a->Cout, 320) * 320;
+        const int64_t t192 = uda_cdiv(P, 64) * (c192 / 192), t320 = uda_cdiv(P, 64) * (c320 / 320);
+        if (c192 <= c320 && t192 <= 512) few_w = 192;
+        else if (t320 <= 512) few_w = 320;
+    }
+    const bool few = few_w != 0;
     if (uda_conv_uses_x3(a)) e = launch_conv_x3(k, P, a->x3_src, a->x3_w, st, a->workspace, a->workspace_bytes);
+    else if (few && k.Ktot > 192 && a->ksize == 1 && a->Cout > 128 && few_w == 192) e = launch_conv<1, 3, 2, 2>(k, P, st);
+    else if (few && k.Ktot > 192 && a->ksize == 1 && a->Cout > 128 && few_w == 320) e = launch_conv<1, 5, 2, 2>(k, P, st);
     else if (low && a->Cout <= 64) e = launch_conv<1, 1, 2, 2>(k, P, st);
     else if (low && a->Cout <= 128 && (k.Ktot <= 192 || a->Cout <= 96 || (a->ksize >= 2 && k.Kc < IG_BK))) e = launch_conv<1, 2, 2, 2>(k, P, st);
     else if (a->Cout <= 32) e = launch_conv<1, 1, 4, 1>(k, P, st);

@@ -282,3 +282,40 @@ def test_frozen_batchnorm_training_matches_oracle_and_reference_fixture(golden_d
     assert max(fwd.values()) < 2e-4, fwd
     assert stats == 0.0               # frozen statistics: bit-identical to where they started
     model_cases.frozen_grads_ok(grads)
+
+
+def test_fused_grad_accumulation_equals_autograd_accumulation():
+    """Two generator passes under one backward (source + target of a step): inside ``fused_grad_accumulation()`` the second node adds
+    its gradients into ``.grad`` itself (one multi-tensor launch); the sums are AccumulateGrad's, bit for bit, and outside the scope
+    nothing changes (``torch.autograd.grad`` still receives every gradient)."""
+    m = _model()
+    m.train()
+    g = torch.Generator().manual_seed(3)
+    xa, xb = torch.randn(2, 3, 64, 64, generator=g), torch.randn(2, 3, 64, 64, generator=g)
+    masks = [model_cases.random_masks(2, 64, 64, seed) for seed in (11, 12)] if hasattr(model_cases, "random_masks") else None
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def loss():
+        total = 0.0
+        for i, x in enumerate((xa, xb)):
+            if masks is not None:
+                m.set_dropout_masks(masks[i])
+            o = m(x)
+            total = total + o[0].square().mean() + o[4].mean() + o[1].sum() * 1e-3
+        return total
+
+    m.set_dropout_seed(7)
+    m._engine_override.rng_offset = 0
+    loss().backward(inputs=params)
+    ref = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    m._engine_override.rng_offset = 0
+    with m.fused_grad_accumulation():
+        loss().backward(inputs=params)
+    assert not m._fuse_accum
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, r)
+    m._engine_override.rng_offset = 0
+    got = torch.autograd.grad(loss(), params, allow_unused=True)
+    assert all(a is not None for a in got)

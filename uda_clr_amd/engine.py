@@ -888,9 +888,12 @@ class GeneratorEngine:
             d_x1b.zero_()
         if gx1b is not None:
             d_x1b.add_(_rows(gx1b))
-        d_xf = torch.zeros(P4, 308, dtype=torch.float32, device=x.device)
-        if gxf is not None:
-            d_xf[:, :305].add_(_rows(gxf))
+        if gxf is not None:           # (the usual case: the prototype losses read x_feature) - its gradient starts the buffer, no zero fill + add
+            d_xf = torch.empty(P4, 308, dtype=torch.float32, device=x.device)
+            d_xf[:, :305].copy_(_rows(gxf))
+            d_xf[:, 305:].zero_()
+        else:
+            d_xf = torch.zeros(P4, 308, dtype=torch.float32, device=x.device)
         if gxbu is not None:
             d_xf[:, :304].add_(_rows(gxbu))
         if gx2b is not None:

@@ -47,7 +47,17 @@ class _GeneratorFn(torch.autograd.Function):
         G = ctx.engine.backward(ctx.ectx, grads)
         ctx.module._forget(ctx.ectx)          # its activations are consumed; parameters are about to change
         ctx.ectx = None
-        return (None, None, None, None) + tuple(G.get(k) for k in ctx.keys)
+        out = [G.get(k) for k in ctx.keys]
+        if ctx.module._fuse_accum:
+            # inside fused_grad_accumulation(): a parameter that already holds a gradient (the other generator pass of this step ran its
+            # backward first) takes this one with ONE multi-tensor add instead of ~190 AccumulateGrad launches; autograd gets None for it
+            state = ctx.module._flat_state()
+            idx = [i for i, k in enumerate(ctx.keys) if out[i] is not None and state[k].grad is not None and state[k].requires_grad]
+            if idx:
+                torch._foreach_add_([state[ctx.keys[i]].grad for i in idx], [out[i] for i in idx])
+                for i in idx:
+                    out[i] = None
+        return (None, None, None, None) + tuple(out)
 
 
 class DeepLab(Holder):
@@ -70,6 +80,7 @@ class DeepLab(Holder):
         self._engine_override = None      # tests only: an engine bound to their torch kernel spec
         self._next_masks = None           # tests only: injected dropout keep-masks for one forward
         self._wshare = None               # inside shared_weight_layouts(): {(key, kind): kernel-side layout} of the current parameters
+        self._fuse_accum = False          # inside fused_grad_accumulation(): backward adds into existing .grad itself (one launch)
         if freeze_bn:
             self.freeze_bn()
 
@@ -131,6 +142,23 @@ class DeepLab(Holder):
                 yield self
             finally:
                 self._wshare = keep
+        return scope()
+
+    def fused_grad_accumulation(self):
+        """Context manager around a ``backward()`` that runs SEVERAL generator passes' backward nodes (source + target of one
+        step): the second node adds its parameter gradients into the ``.grad`` the first one left with one multi-tensor launch and
+        hands autograd ``None`` for them (same sums as AccumulateGrad's per-parameter adds).  Only for ``backward()`` calls that
+        accumulate into ``.grad`` - NOT around ``torch.autograd.grad`` (which expects the gradients returned) and not with
+        per-parameter gradient hooks.  ``Trainer_prototype_full`` holds it around ``loss_all.backward``."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            keep, self._fuse_accum = self._fuse_accum, True
+            try:
+                yield self
+            finally:
+                self._fuse_accum = keep
         return scope()
 
     def note_params_changed(self):

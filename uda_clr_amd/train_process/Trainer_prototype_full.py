@@ -288,7 +288,9 @@ class Trainer(TrainerBase):
             if self.src_reg:
                 loss_all = loss_all + self.src_reg_weight * self.loss_src_reg
         self._grad_mode((dis, dis2), "input")
-        loss_all.backward(inputs=gen_params, retain_graph=True)
+        import contextlib
+        with (gen.fused_grad_accumulation() if hasattr(gen, "fused_grad_accumulation") else contextlib.nullcontext()):
+            loss_all.backward(inputs=gen_params, retain_graph=True)       # (T and S passes: the second adds into .grad in one launch)
         self._grad_mode((dis, dis2), "auto")
         if self.use_trg_cons and intra_loss is not None and self.retrify_pesudo:             # Appendix B (unpinned)
             # augmented consistency: pseudo labels of the clean target prediction supervise the prediction on

@@ -311,11 +311,27 @@ def test_fused_grad_accumulation_equals_autograd_accumulation():
     for p in params:
         p.grad = None
     m._engine_override.rng_offset = 0
-    with m.fused_grad_accumulation():
-        loss().backward(inputs=params)
-    assert not m._fuse_accum
+    calls, orig = [], torch._foreach_add_
+
+    def spy(a, b, *args, **kw):
+        calls.append(len(a))
+        return orig(a, b, *args, **kw)
+    torch._foreach_add_ = spy
+    try:
+        with m.fused_grad_accumulation():
+            loss().backward(inputs=params)
+    finally:
+        torch._foreach_add_ = orig
+    assert not m._fuse_accum and m._accum_stash is None
+    assert max(calls) == len(params), "the second pass must have added all its gradients with one multi-tensor launch"
     for p, r in zip(params, ref):
         assert torch.equal(p.grad, r)
+    # a second run inside a fresh scope accumulates into .grad as autograd always does
+    m._engine_override.rng_offset = 0
+    with m.fused_grad_accumulation():
+        loss().backward(inputs=params)
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, r + r)
     m._engine_override.rng_offset = 0
     got = torch.autograd.grad(loss(), params, allow_unused=True)
     assert all(a is not None for a in got)

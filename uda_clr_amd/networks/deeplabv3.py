@@ -49,14 +49,23 @@ class _GeneratorFn(torch.autograd.Function):
         ctx.ectx = None
         out = [G.get(k) for k in ctx.keys]
         if ctx.module._fuse_accum:
-            # inside fused_grad_accumulation(): a parameter that already holds a gradient (the other generator pass of this step ran its
-            # backward first) takes this one with ONE multi-tensor add instead of ~190 AccumulateGrad launches; autograd gets None for it
-            state = ctx.module._flat_state()
-            idx = [i for i, k in enumerate(ctx.keys) if out[i] is not None and state[k].grad is not None and state[k].requires_grad]
-            if idx:
-                torch._foreach_add_([state[ctx.keys[i]].grad for i in idx], [out[i] for i in idx])
-                for i in idx:
-                    out[i] = None
+            # inside fused_grad_accumulation(): autograd would sum the gradients the generator passes of ONE backward run send to the
+            # same parameter in its input buffers, one add launch per parameter (~190).  Instead the first node of a run remembers
+            # the tensors it hands over and every later node adds its gradients INTO them with one multi-tensor launch and hands
+            # over None (an absent contribution).  The references are dropped right away so that AccumulateGrad still holds the last
+            # one and keeps the tensor instead of cloning it; an engine callback clears them at the end of the run in any case.
+            module = ctx.module
+            stash = module._accum_stash
+            if stash is None:
+                module._accum_stash = {k: g for k, g in zip(ctx.keys, out) if g is not None}
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: setattr(module, "_accum_stash", None))
+            else:
+                idx = [i for i, k in enumerate(ctx.keys) if out[i] is not None and k in stash]
+                if idx:
+                    torch._foreach_add_([stash[ctx.keys[i]] for i in idx], [out[i] for i in idx])
+                    for i in idx:
+                        out[i] = None
+                module._accum_stash = None
         return (None, None, None, None) + tuple(out)
 
 
@@ -80,7 +89,8 @@ class DeepLab(Holder):
         self._engine_override = None      # tests only: an engine bound to their torch kernel spec
         self._next_masks = None           # tests only: injected dropout keep-masks for one forward
         self._wshare = None               # inside shared_weight_layouts(): {(key, kind): kernel-side layout} of the current parameters
-        self._fuse_accum = False          # inside fused_grad_accumulation(): backward adds into existing .grad itself (one launch)
+        self._fuse_accum = False          # inside fused_grad_accumulation(): the passes of one backward run sum their gradients themselves
+        self._accum_stash = None          # ... {key: gradient tensor the first pass of the current run handed to autograd}
         if freeze_bn:
             self.freeze_bn()
 
@@ -146,10 +156,10 @@ class DeepLab(Holder):
 
     def fused_grad_accumulation(self):
         """Context manager around a ``backward()`` that runs SEVERAL generator passes' backward nodes (source + target of one
-        step): the second node adds its parameter gradients into the ``.grad`` the first one left with one multi-tensor launch and
-        hands autograd ``None`` for them (same sums as AccumulateGrad's per-parameter adds).  Only for ``backward()`` calls that
-        accumulate into ``.grad`` - NOT around ``torch.autograd.grad`` (which expects the gradients returned) and not with
-        per-parameter gradient hooks.  ``Trainer_prototype_full`` holds it around ``loss_all.backward``."""
+        step): the later node adds its parameter gradients into the tensors the first one handed to autograd, with one multi-tensor
+        launch, and hands over ``None`` (same sums as autograd's per-parameter input-buffer adds, bit for bit).  Only around
+        ``backward()`` / ``autograd.grad`` calls that want the SUM over the passes; ``Trainer_prototype_full`` holds it around
+        ``loss_all.backward``."""
         import contextlib
 
         @contextlib.contextmanager
@@ -159,6 +169,7 @@ class DeepLab(Holder):
                 yield self
             finally:
                 self._fuse_accum = keep
+                self._accum_stash = None
         return scope()
 
     def note_params_changed(self):

@@ -31,8 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the global loads of chunk c + 2 are in flight, one barrier per chunk (round 3: the long-K project convs of the 32x32-map layers run
 // one workgroup per CU and sat at the global-load latency of every chunk: 12 chunks x 1.7 us against 0.47 us of MFMA work each).
 // PIPE = false: one image, loads one chunk ahead, two barriers per chunk (short K: fewer registers and half the LDS per workgroup).
+// Registers: without a bound the compiler spends 125 VGPRs + 48 AGPRs on <1,3,4,1> (two workgroups per CU, and the output-bound expand
+// convs wrote at 2.4 TB/s: load, MFMA and store phases of two workgroups do not cover each other); the lean form is asked for 4 / 3
+// waves per SIMD by accumulator count, the pipelined form keeps 2.
+#define IGC_MIN_WAVES(TM, TN, PIPE) ((PIPE) ? 2 : ((TM) * (TN) <= 3 ? 4 : 3))
 template <int TM, int TN, int WM, int WN, bool PIPE = false>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
+__global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_kernel(ConvKArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int TILE = (BM + BN) * IG_LD;

@@ -102,6 +102,35 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwArgs a) {
 // back with ds_read_b128.  (The first version re-read and re-transformed every input 9 times from
 // L1/L2: 1.3-2.1 TB/s of algorithmic bytes; this one is bounded by the 1.3-1.6x halo over-read.)
 #define DWT_CB 32
+// Halo tile into LDS: every thread's loads are issued back to back with clamped coordinates (the value of an out-of-image position is
+// replaced afterwards) - with the bounds test AROUND the load a thread had one load in flight at a time and a workgroup spent six to
+// twelve load latencies on staging (the tiled kernels streamed at 2.4-3.7 TB/s).
+template <int S, int TH, int TW>
+__device__ __forceinline__ void dw_stage_tile(float* tile, const float* xb, int64_t ldx, int H, int W, int gy0, int gx0, int IH, int IW, bool cok,
+                                              const Xf4& xf, bool has_xf, int act, float4 bval, int pl, int cg) {
+    constexpr int MAXL = (((TH - 1) * S + 5) * ((TW - 1) * S + 5) + 31) / 32;      // dilation <= 2
+    float4 v[MAXL];
+    const int npix = IH * IW;
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        const int idx = min(pl + 32 * l, npix - 1);
+        const int iy = idx / IW, ix = idx - iy * IW;
+        const int gy = min(max(gy0 + iy, 0), H - 1), gx = min(max(gx0 + ix, 0), W - 1);
+        v[l] = uda_ld4(xb + ((int64_t)gy * W + gx) * ldx);
+    }
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        const int idx = pl + 32 * l;
+        if (idx < npix) {
+            const int iy = idx / IW, ix = idx - iy * IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            const bool in = cok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float4 u = in ? dw_transform(v[l], xf, has_xf, act) : bval;
+            uda_st4(&tile[idx * DWT_CB + cg * 4], u);
+        }
+    }
+}
+
 template <int S, int TH, int TW>
 __global__ __launch_bounds__(256) void dwconv_fwd_tiled_kernel(DwArgs a, int tilesX, int tilesY) {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [IH*IW][32] then [32 lanes][2][32] for the stats
@@ -125,15 +154,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_tiled_kernel(DwArgs a, int til
         bval = make_float4(uda_act(xf.sh[0], act), uda_act(xf.sh[1], act), uda_act(xf.sh[2], act), uda_act(xf.sh[3], act));
     // ---- stage the halo tile
     const int gy0 = oy0 * S - d, gx0 = ox0 * S - d;
-    const float* xb = a.src.x + (int64_t)n * H * W * a.src.ldx + c0;
-    for (int idx = pl; idx < IH * IW; idx += 32) {
-        const int iy = idx / IW, ix = idx - iy * IW;
-        const int gy = gy0 + iy, gx = gx0 + ix;
-        float4 u = bval;
-        if (cok && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            u = dw_transform(uda_ld4(xb + ((int64_t)gy * W + gx) * a.src.ldx), xf, has_xf, act);
-        uda_st4(&tile[idx * DWT_CB + cg * 4], u);
-    }
+    const float* xb = a.src.x + (int64_t)n * H * W * a.src.ldx + (cok ? c0 : 0);
+    dw_stage_tile<S, TH, TW>(tile, xb, a.src.ldx, H, W, gy0, gx0, IH, IW, cok, xf, has_xf, act, bval, pl, cg);
     float4 w[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = cok ? uda_ld4(a.w9c + t * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -198,25 +220,25 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(DwArgs a, int t
     if (a.border_mode == 1)
         bval = make_float4(uda_act(xf.sh[0], act), uda_act(xf.sh[1], act), uda_act(xf.sh[2], act), uda_act(xf.sh[3], act));
     const int gy0 = oy0 * S - d, gx0 = ox0 * S - d;
-    const float* xb = a.src.x + (int64_t)n * H * W * a.src.ldx + c0;
-    for (int idx = pl; idx < IH * IW; idx += 32) {
-        const int iy = idx / IW, ix = idx - iy * IW;
-        const int gy = gy0 + iy, gx = gx0 + ix;
-        float4 u = bval;
-        if (cok && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            u = dw_transform(uda_ld4(xb + ((int64_t)gy * W + gx) * a.src.ldx), xf, has_xf, act);
-        uda_st4(&tile[idx * DWT_CB + cg * 4], u);
-    }
+    const float* xb = a.src.x + (int64_t)n * H * W * a.src.ldx + (cok ? c0 : 0);
+    dw_stage_tile<S, TH, TW>(tile, xb, a.src.ldx, H, W, gy0, gx0, IH, IW, cok, xf, has_xf, act, bval, pl, cg);
     __syncthreads();
     float4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gv[(TH * TW) / 32];           // this thread's dy values, loaded together (clamped positions, zero weight outside)
+#pragma unroll
+    for (int k = 0; k < (TH * TW) / 32; ++k) {
+        const int op = pl + 32 * k;
+        const int oy = min(oy0 + op / TW, a.Ho - 1), ox = min(ox0 + op % TW, a.Wo - 1);
+        gv[k] = uda_ld4(a.dy + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * a.lddy + (cok ? c0 : 0));
+    }
 #pragma unroll
     for (int k = 0; k < (TH * TW) / 32; ++k) {
         const int op = pl + 32 * k;
         const int oy = op / TW, ox = op % TW;
         if (!cok || oy0 + oy >= a.Ho || ox0 + ox >= a.Wo) continue;
-        const float4 g = uda_ld4(a.dy + (((int64_t)n * a.Ho + oy0 + oy) * a.Wo + ox0 + ox) * a.lddy + c0);
+        const float4 g = gv[k];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -306,6 +328,30 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
         const int iw = (int)(p % W), ih = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
         const int c0 = cg * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (stride == 2 && dil == 1) {
+            // stride 2 (the four down-sampling blocks): an even coordinate is read by the centre tap only, an odd one by the two outer
+            // taps - at most 2 x 2 taps exist.  The four candidates are loaded back to back from clamped positions and weighted 0
+            // where they do not exist (behind the general loop's tests a thread had one load in flight at a time).
+            const int khA = (ih & 1) ? 0 : 1, ohA = (ih + 1) >> 1, ohB = (ih - 1) >> 1;        // tap khA reads oh = (ih + 1 - khA) / 2; B: kh = 2
+            const int kwA = (iw & 1) ? 0 : 1, owA = (iw + 1) >> 1, owB = (iw - 1) >> 1;
+            const int oha = (ih & 1) ? ohA : (ih >> 1), owa = (iw & 1) ? owA : (iw >> 1);
+            const bool hA = oha < Ho, hB = (ih & 1) && ohB >= 0 && ohB < Ho;
+            const bool wA = owa < Wo, wB = (iw & 1) && owB >= 0 && owB < Wo;
+            const int r0 = min(oha, Ho - 1), r1 = min(max(ohB, 0), Ho - 1), q0 = min(owa, Wo - 1), q1 = min(max(owB, 0), Wo - 1);
+            const float* base = dy + (int64_t)n * Ho * Wo * lddy + c0;
+            const float4 g00 = uda_ld4(base + ((int64_t)r0 * Wo + q0) * lddy), g01 = uda_ld4(base + ((int64_t)r0 * Wo + q1) * lddy);
+            const float4 g10 = uda_ld4(base + ((int64_t)r1 * Wo + q0) * lddy), g11 = uda_ld4(base + ((int64_t)r1 * Wo + q1) * lddy);
+            const float4 w00 = uda_ld4(w9c + (khA * 3 + kwA) * C + c0), w01 = uda_ld4(w9c + (khA * 3 + 2) * C + c0);
+            const float4 w10 = uda_ld4(w9c + (2 * 3 + kwA) * C + c0), w11 = uda_ld4(w9c + (2 * 3 + 2) * C + c0);
+            const float k00 = (hA && wA) ? 1.f : 0.f, k01 = (hA && wB) ? 1.f : 0.f, k10 = (hB && wA) ? 1.f : 0.f, k11 = (hB && wB) ? 1.f : 0.f;
+            // same order as the general loop: kh ascending, kw ascending
+            acc.x = k00 * (w00.x * g00.x); acc.y = k00 * (w00.y * g00.y); acc.z = k00 * (w00.z * g00.z); acc.w = k00 * (w00.w * g00.w);
+            acc.x += k01 * (w01.x * g01.x); acc.y += k01 * (w01.y * g01.y); acc.z += k01 * (w01.z * g01.z); acc.w += k01 * (w01.w * g01.w);
+            acc.x += k10 * (w10.x * g10.x); acc.y += k10 * (w10.y * g10.y); acc.z += k10 * (w10.z * g10.z); acc.w += k10 * (w10.w * g10.w);
+            acc.x += k11 * (w11.x * g11.x); acc.y += k11 * (w11.y * g11.y); acc.z += k11 * (w11.z * g11.z); acc.w += k11 * (w11.w * g11.w);
+            uda_st4(dx + p * lddx + c0, acc);
+            continue;
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int nh = ih - (kh - 1) * dil;

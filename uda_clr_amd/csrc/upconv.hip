@@ -230,10 +230,19 @@ __global__ __launch_bounds__(256) void upconv_fwd_tile_kernel(const float* __res
         const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)((int64_t)N * h * w * ldg * 4), 0x00020000);
         const int ldg4 = (int)ldg * 4, nload = R * RC * 72;
         const int base = ((n * h) * w) * ldg4 + (cs * UPT_CS) * 4;
-        for (int i = tid; i < nload; i += 256) {
-            const int cg = i & 7, q = i >> 3, pc = q / 9, tap = q - pc * 9, r = pc / RC, c = pc - r * RC;
-            const int hh = min(hlo + r, h - 1), ww = min(wlo + c, w - 1);            // (rows / columns beyond the image: never blended)
-            foot[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gres, base + (hh * w + ww) * ldg4 + cg * 16, tap * C * 4, 0));
+        // six loads in flight per thread (a load followed by its own LDS store in one loop body keeps ONE in flight)
+        for (int i0 = tid; i0 < nload; i0 += 256 * 6) {
+            float4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int i = min(i0 + 256 * u, nload - 1);
+                const int cg = i & 7, q = i >> 3, pc = q / 9, tap = q - pc * 9, r = pc / RC, c = pc - r * RC;
+                const int hh = min(hlo + r, h - 1), ww = min(wlo + c, w - 1);        // (rows / columns beyond the image: never blended)
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gres, base + (hh * w + ww) * ldg4 + cg * 16, tap * C * 4, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+                if (i0 + 256 * u < nload) foot[i0 + 256 * u] = v[u];
         }
     }
     if (tid < UPT_TH + 2) {                      // row table
@@ -515,14 +524,22 @@ __global__ __launch_bounds__(256) void upconv_bwd_wave_kernel(const float* __res
             const float* row = dy + (((int64_t)n * H + oh) * W) * ldy + lane * 4;
             float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0;
             float bm = __int_as_float(B(ow0 - 1)), bc = __int_as_float(B(ow0));
-            for (int ow = ow0; ow <= ow1; ++ow) {
-                const float bp = __int_as_float(B(ow + 1));
-                const float4 v = uda_ld4(row + (int64_t)ow * ldy);
-                t0.x += bm * v.x; t0.y += bm * v.y; t0.z += bm * v.z; t0.w += bm * v.w;      // tap tw = 0 sits at ow - 1
-                t1.x += bc * v.x; t1.y += bc * v.y; t1.z += bc * v.z; t1.w += bc * v.w;
-                t2.x += bp * v.x; t2.y += bp * v.y; t2.z += bp * v.z; t2.w += bp * v.w;
-                bm = bc;
-                bc = bp;
+            for (int owb = ow0; owb <= ow1; owb += 4) {           // four columns' loads in flight (clamped; a column beyond ow1 has weights 0)
+                float4 v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v4[u] = uda_ld4(row + (int64_t)min(owb + u, ow1) * ldy);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ow = owb + u;
+                    const float bp = __int_as_float(B(ow + 1));
+                    const float4 v = v4[u];
+                    const float km = ow <= ow1 ? bm : 0.f, kc = ow <= ow1 ? bc : 0.f, kp = ow <= ow1 ? bp : 0.f;
+                    t0.x += km * v.x; t0.y += km * v.y; t0.z += km * v.z; t0.w += km * v.w;      // tap tw = 0 sits at ow - 1
+                    t1.x += kc * v.x; t1.y += kc * v.y; t1.z += kc * v.z; t1.w += kc * v.w;
+                    t2.x += kp * v.x; t2.y += kp * v.y; t2.z += kp * v.z; t2.w += kp * v.w;
+                    bm = bc;
+                    bc = bp;
+                }
             }
             const float a3[3] = {a0, a1, a2};
 #pragma unroll

@@ -995,6 +995,18 @@ CASES += [
     ("wgrad1x1 1024->256 P=8192 raw (x3 long-K 1x1)", case_wgrad(8, 32, 32, 1024, 256, 1, 1, lazy=False)),
     ("wgrad1x1 2048->512 P=4624 relu (x3 long-K 1x1)", case_wgrad(4, 34, 34, 2048, 512, 1, 1)),
 ]
+# short-K 1x1 convs over >= 32768 pixels: the barrier-free one-wave-per-32-pixels kernel (conv1x1_stream_kernel)
+CASES += [
+    ("conv1x1 16->96 P=33800 relu6 stats (stream kernel, ragged last tile)", case_conv(2, 130, 130, 16, 96, 1, 1)),
+    ("conv1x1 16->90 P=33800 raw addend no stats (stream kernel, ragged columns)", case_conv(2, 130, 130, 16, 90, 1, 1, lazy=False, addend=True, stats=False)),
+    ("conv1x1 24->144 P=40000 raw addend (stream kernel, two column groups)", case_conv(1, 200, 200, 24, 144, 1, 1, lazy=False, addend=True)),
+    ("conv1x1 24->48 P=36100 relu stats (stream kernel)", case_conv(1, 190, 190, 24, 48, 1, 1)),
+    ("conv1x1 32->192 P=36300 relu stats addend (stream kernel, two column groups)", case_conv(3, 110, 110, 32, 192, 1, 1, addend=True)),
+    ("conv1x1 32->130 P=32768 raw (stream kernel, second group ragged)", case_conv(2, 128, 128, 32, 130, 1, 1, lazy=False)),
+    ("conv1x1 32->192 P=262144 relu6 stats (stream kernel, two column groups)", case_conv(4, 256, 256, 32, 192, 1, 1)),
+    ("conv1x1 16->32 P=33800 raw addend (stream kernel, one block)", case_conv(2, 130, 130, 16, 32, 1, 1, lazy=False, addend=True, stats=False)),
+    ("conv1x1 24->96 P=40000 raw addend (stream kernel, three blocks)", case_conv(1, 200, 200, 24, 96, 1, 1, lazy=False, addend=True, stats=False)),
+]
 # stride 2 on the wide tiles: the loaders walk the strided output grid (ResNet-101 layer2.0 / layer3.0 conv2, resnet.py:66, and their
 # weight gradients; the 1x1 form is the shortcut conv, resnet.py:93)
 CASES += [

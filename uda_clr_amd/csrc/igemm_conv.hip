@@ -20,6 +20,7 @@
 //   for BOTH operands, so one ds_read_b128 per operand row feeds 4 MFMAs.
 //   Tiles are ordered n-fastest and XCD-chunked (uda_xcd_remap) so the two N tiles of a pixel
 //   tile and spatially adjacent pixel tiles share one XCD's L2.
+#include <algorithm>
 #include "common.h"
 #include <stdlib.h>
 #include "igemm_args.h"
@@ -492,6 +493,171 @@ __global__ __launch_bounds__(256) void conv_heads_kernel(ConvKArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Short-K 1x1 convs over many pixels (the backbone's expand convs 16 -> 96, 24 -> 144, 32 -> 192 and the input gradients of their
+// project twins, mobilenet.py:43-57): output-bound - 0.5 GB written for 0.07 GB read - and the tiled kernel above wrote at 2.4 TB/s
+// whatever its options, because one workgroup spends ~4000 instructions of generic staging / epilogue code on 48 MFMAs.  Here:
+//   * one WAVE owns 32 pixels x all Cout columns per trip of a persistent loop; no LDS, no barriers;
+//   * its operands go straight into the MFMA register layout: lane (row r = l & 31, half h = l >> 5) loads channels [h K/2, (h+1) K/2)
+//     of its pixel with K/8 16-byte loads - the contraction order is permuted (k-slot 0 of step kk is channel kk, k-slot 1 channel
+//     K/2 + kk; the weights, held in registers for the whole launch, are read the same way), which changes nothing but the rounding order;
+//   * the accumulators leave as 4-byte stores of two 128-byte row segments per instruction through a buffer descriptor (a row or
+//     column outside the matrix gets an out-of-range offset), the addend arrives the same way;
+//   * the BatchNorm statistics stay in registers over the loop and are added once per wave (fp64 atomics).
+// ~350 instructions per 32 pixels instead of ~1000.
+// A wave keeps ONE group of NB column blocks for the whole launch (its weights live in registers): wave w serves column group w % ngroups
+// and the pixel tiles w / ngroups, + nwaves / ngroups, ... (Cout = 192 = two groups of 96: 48 weight + 48 accumulator registers per wave
+// instead of 96 + 96, two waves per SIMD).
+template <int KH, int NB>      // KH = K / 2 channels per lane (8, 12, 16), NB = 32-column blocks per group
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvKArgs a, int64_t P, int ntiles, int ngroups) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const int K = 2 * KH;
+    const int grp = wave % ngroups, col0 = grp * (NB * 32);
+    // weights: b[nb][kk] = w[col][h KH + kk], col = col0 + 32 nb + r (zero beyond Cout)
+    float b[NB][KH];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col0 + nb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < a.Cout) v = uda_ld4(a.w + (int64_t)col * K + h * KH + 4 * q);
+            b[nb][4 * q] = v.x; b[nb][4 * q + 1] = v.y; b[nb][4 * q + 2] = v.z; b[nb][4 * q + 3] = v.w;
+        }
+    }
+    const bool has_xf = a.src.scale != nullptr;      // (scale and shift are re-read per tile - 2 KH / 4 cached loads - instead of held in 2 KH registers)
+    const bool xf16 = has_xf && ((reinterpret_cast<uintptr_t>(a.src.scale) | reinterpret_cast<uintptr_t>(a.src.shift)) & 15) == 0;
+    const float alo = a.src.act == ACT_NONE ? -INFINITY : 0.f, ahi = a.src.act == ACT_RELU6 ? 6.f : INFINITY;
+    // statistics: fp32 over one tile's 16 rows per lane (as long a chain as the tiled kernel's), fp64 across the tiles of the loop - an
+    // fp32 chain over all of a wave's tiles (hundreds of values) showed up as 5x the noise in the near-cancelling BN-affine gradients
+    double s1[NB], s2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) s1[nb] = s2[nb] = 0.0;
+    constexpr int OOB = 0x7ffffff0;
+    const int ldy4 = (int)a.ldy * 4, lda4 = (int)a.ld_add * 4;
+    for (int t = wave / ngroups; t < ntiles; t += nwaves / ngroups) {
+        const int64_t p0 = (int64_t)t * 32;
+        const int64_t p = min(p0 + r, P - 1);                          // (rows beyond the matrix: computed, never stored or counted)
+        float av[KH];
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            const float4 v = uda_ld4(a.src.x + p * a.src.ldx + h * KH + 4 * q);
+            av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+        }
+        if (has_xf) {
+#pragma unroll
+            for (int q = 0; q < KH / 4; ++q) {
+                float4 sc, sh;
+                if (xf16) {
+                    sc = uda_ld4(a.src.scale + h * KH + 4 * q);
+                    sh = uda_ld4(a.src.shift + h * KH + 4 * q);
+                } else {
+                    const float* ps = a.src.scale + h * KH + 4 * q;
+                    const float* pt = a.src.shift + h * KH + 4 * q;
+                    sc = make_float4(ps[0], ps[1], ps[2], ps[3]);
+                    sh = make_float4(pt[0], pt[1], pt[2], pt[3]);
+                }
+                av[4 * q] = av[4 * q] * sc.x + sh.x; av[4 * q + 1] = av[4 * q + 1] * sc.y + sh.y;
+                av[4 * q + 2] = av[4 * q + 2] * sc.z + sh.z; av[4 * q + 3] = av[4 * q + 3] * sc.w + sh.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KH; ++j) av[j] = __builtin_amdgcn_fmed3f(av[j], alo, ahi);
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b[nb][kk], acc[nb], 0, 0, 0);
+        // C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+        const int rows_left = (int)min((int64_t)32, P - p0);
+        const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(a.y + p0 * a.ldy, 0, ((rows_left - 1) * (int)a.ldy + a.Cout) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t adres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.addend ? a.addend + p0 * a.ld_add : a.y), 0, a.addend ? ((rows_left - 1) * (int)a.ld_add + a.Cout) * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = col0 + nb * 32 + r;
+            const bool cok = col < a.Cout;
+            float ad[16];                                              // the block's addend values, loaded together
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ad[e] = 0.f;
+            if (a.addend) {                                            // (uniform)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = (e & 3) + 8 * (e >> 2);
+                    const bool ok = cok && (rl + 4 * h) < rows_left;
+                    ad[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(adres, ok ? (4 * h) * lda4 + col * 4 : OOB, rl * lda4, 0));
+                }
+            }
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2);                 // + 4 h (per lane)
+                const float v = acc[nb][e];
+                const bool ok = cok && (rl + 4 * h) < rows_left;
+                t1 += ok ? v : 0.f;
+                t2 += ok ? v * v : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + ad[e]), yres, ok ? (4 * h) * ldy4 + col * 4 : OOB, rl * ldy4, 0);
+            }
+            s1[nb] += (double)t1;
+            s2[nb] += (double)t2;
+        }
+    }
+    if (a.stats) {
+        double* dst = a.stats + (int64_t)(wave % UDA_STAT_SLOTS) * 2 * a.Cout;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const double t1 = s1[nb] + __shfl_xor(s1[nb], 32), t2 = s2[nb] + __shfl_xor(s2[nb], 32);
+            const int col = col0 + nb * 32 + r;
+            if (h == 0 && col < a.Cout) {
+                atomicAdd(&dst[col], t1);
+                atomicAdd(&dst[a.Cout + col], t2);
+            }
+        }
+    }
+}
+
+template <int KH, int NB>
+static int launch_stream(ConvKArgs& k, int64_t P, hipStream_t st) {
+    const int ntiles = (int)uda_cdiv(P, 32);
+    static int resident_dev[UDA_MAX_DEVICES] = {};          // workgroups of this kernel the device holds at a time
+    int& resident = resident_dev[uda_device_slot()];
+    auto fn = conv1x1_stream_kernel<KH, NB>;
+    if (!resident) {
+        int dev = 0, ncu = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, 0) != hipSuccess || ncu < 1 || per_cu < 1)
+            return uda_set_error("conv1x1_stream: cannot query the device's residency");
+        resident = ncu * per_cu;
+    }
+    const int ngroups = uda_cdiv(k.Cout, NB * 32);                       // 1 or 2 (conv_stream_shape)
+    int grid = (int)std::min<int64_t>(resident, uda_cdiv((int64_t)ntiles * ngroups, 4));
+    if (ngroups == 2 && grid > 1) grid &= ~1;                            // (waves per launch divisible by the groups: 4 per workgroup)
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, k, P, ntiles, ngroups);
+    UDA_LAUNCH_CHECK("conv1x1_stream");
+    return 0;
+}
+
+// the short-K streaming form applies: 1x1, stride 1, K = Cin in {16, 24, 32}, no keep-mask, no bias, >= 32768 pixels, aligned rows
+static int conv_stream_shape(const uda_conv_args_t* a, int64_t P) {
+    static const int on = getenv("UDA_CONV_STREAM") ? atoi(getenv("UDA_CONV_STREAM")) : 1;      // A/B switch
+    if (!on || a->ksize != 1 || (a->stride > 1) || a->src.mask || a->bias || P < 32768) return 0;
+    if (!uda_aligned16(a->src.x) || a->src.ldx % 4 || (a->src.C != 16 && a->src.C != 24 && a->src.C != 32)) return 0;
+    if (P * a->ldy >= ((int64_t)1 << 29) || (a->addend && P * a->ld_add >= ((int64_t)1 << 29))) return 0;
+    const int C = a->src.C, Cout = a->Cout;
+    if (C == 16 && Cout <= 32) return 5;
+    if (C == 16 && Cout <= 96) return 1;
+    if (C == 24 && Cout <= 64) return 2;
+    if (C == 24 && Cout <= 96) return 6;
+    if (C == 24 && Cout <= 160) return 3;
+    if (C == 32 && Cout > 96 && Cout <= 192 && P >= 262144) return 4;      // (at 65536 pixels, and towards few columns, the tiled kernel is as fast or faster)
+    return 0;
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -585,6 +751,15 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     UDA_REQUIRE((Pin + 128) * a->src.ldx < ((int64_t)1 << 29) && (Pin + 128) * (a->src.mask ? a->src.ldm : 1) < ((int64_t)1 << 31),
                 "uda_conv_fwd: operand too large for 32-bit byte offsets (P * ld must stay below 2^29 elements)");
     int e;
+    switch (conv_stream_shape(a, P)) {
+        case 1: return launch_stream<8, 3>(k, P, st);
+        case 2: return launch_stream<12, 2>(k, P, st);
+        case 3: return launch_stream<12, 5>(k, P, st);      // 144 columns in one group of five blocks
+        case 4: return launch_stream<16, 3>(k, P, st);      // two column groups of 96
+        case 5: return launch_stream<8, 1>(k, P, st);
+        case 6: return launch_stream<12, 3>(k, P, st);
+        default: break;
+    }
     if (sd != 1) {       // only the wide-tile kernels walk a strided output grid
         const bool wide = conv_is_wide(a, k.Kc, k.Ktot) && a->Cout > 96 && !(k.Ktot <= 192 || (a->ksize >= 2 && k.Kc < IG_BK));
         UDA_REQUIRE(wide, "uda_conv_fwd: stride 2 is built on the wide-tile kernels only (Cout > 96, K > 192)");

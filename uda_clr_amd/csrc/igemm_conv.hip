@@ -36,8 +36,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // convs wrote at 2.4 TB/s: load, MFMA and store phases of two workgroups do not cover each other); the lean form is asked for 4 / 3
 // waves per SIMD by accumulator count, the pipelined form keeps 2.
 #define IGC_MIN_WAVES(TM, TN, PIPE) ((PIPE) ? 2 : ((TM) * (TN) <= 3 ? 4 : 3))
-template <int TM, int TN, int WM, int WN, bool PIPE = false>
-__global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_kernel(ConvKArgs a) {
+// XF: -1 = general (any kernel size, transform and keep-mask decided at run time); 0 / 1 = 1x1 conv without a keep-mask, 0 also without
+// transform or activation (a gradient matrix): the tap arithmetic, the four mask loads and - for 0 - the eight coefficient loads per
+// chunk and thread are not compiled in (every load of the general form is unconditional so that the compiler can count them; the
+// price was ~20 load instructions per chunk where 7 carry data).
+template <int TM, int TN, int WM, int WN, bool PIPE = false, int XF = -1>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int TILE = (BM + BN) * IG_LD;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_k
         bool& c_kval = r.c_kval;
         const int k0 = chunk * IG_BK + kv;          // position in the weight row
         int t = 0, ci = k0;
-        if (a.ksize >= 2) {
+        if (XF < 0 && a.ksize >= 2) {
             if (a.Kc >= IG_BK) {                     // tap-chunked K: chunk = cc * T + t
                 const int T = a.ksize * a.ksize;
                 t = chunk % T;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_k
         c_kval = k0 < a.Ktot && ci < a.Kc;
         c_ci = ci;
         int dh = 0, dw = 0;
-        if (a.ksize >= 2) {
+        if (XF < 0 && a.ksize >= 2) {
             const int th = a.ksize == 3 ? t / 3 : t >> 1;
             dh = (th - a.cen) * a.dil;
             dw = (t - th * a.ksize - a.cen) * a.dil;
@@ -127,8 +131,13 @@ __global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_k
         // coefficients only when there is a transform and zeroes the lanes beyond C itself - no condition, no select here)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            xf.sc[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scres, (ci + j) * 4, 0, 0));
-            xf.sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shres, (ci + j) * 4, 0, 0));
+            if (XF != 0) {
+                xf.sc[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scres, (ci + j) * 4, 0, 0));
+                xf.sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shres, (ci + j) * 4, 0, 0));
+            } else {
+                xf.sc[j] = 1.f;
+                xf.sh[j] = 0.f;
+            }
         }
         aok = 0;
 #pragma unroll
@@ -138,7 +147,8 @@ __global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_k
             // buffer loads: an out-of-range offset returns zeros (no branch around the load)
             const int q = (int)(m0 + lrow + 32 * i) + dh * W + dw;
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (q * (int)a.src.ldx + ci) * 4 : OOB, 0, 0));
-            amask[i] = __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * (int)a.src.ldm + ci : OOB, 0, 0);      // (no mask: a zero-size descriptor)
+            if (XF < 0) amask[i] = __builtin_amdgcn_raw_buffer_load_b32(mres, ok ? q * (int)a.src.ldm + ci : OOB, 0, 0);      // (no mask: a zero-size descriptor)
+            else amask[i] = 0x01010101u;
             aok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
@@ -156,15 +166,15 @@ __global__ __launch_bounds__(256, IGC_MIN_WAVES(TM, TN, PIPE)) void igemm_conv_k
         const unsigned aok = r.aok;
         const Xf4& xf = r.xf;
         const int c_ci = r.c_ci;
-        const bool has_xf = a.src.scale != nullptr;
-        const int act = a.src.act;
+        const bool has_xf = XF != 0 && a.src.scale != nullptr;
+        const int act = XF == 0 ? ACT_NONE : a.src.act;
         const float ms = a.src.mask_scale;
         // packed pairs (v_pk_fma / v_pk_mul) and a one-instruction clamp for none / ReLU / ReLU6
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 sc01 = {xf.sc[0], xf.sc[1]}, sc23 = {xf.sc[2], xf.sc[3]};       // identity when there is no transform
         const f32x2 sh01 = {xf.sh[0], xf.sh[1]}, sh23 = {xf.sh[2], xf.sh[3]};
         const float alo = act == ACT_NONE ? -INFINITY : 0.f, ahi = act == ACT_RELU6 ? 6.f : INFINITY;
-        const bool masked = a.src.mask != nullptr;
+        const bool masked = XF < 0 && a.src.mask != nullptr;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const bool ok = (aok >> i) & 1u;
@@ -658,6 +668,29 @@ static int conv_stream_shape(const uda_conv_args_t* a, int64_t P) {
     return 0;
 }
 
+template <int TM, int TN, int WM, int WN, bool PIPE, int XF>
+static int launch_conv_one(ConvKArgs& k, hipStream_t st, size_t lds) {
+    auto fn = igemm_conv_kernel<TM, TN, WM, WN, PIPE, XF>;
+    if (lds > 64 * 1024) {                                  // beyond the default dynamic-LDS limit: raise it once per device
+        static bool configured_dev[UDA_MAX_DEVICES] = {};
+        bool& configured = configured_dev[uda_device_slot()];
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return uda_set_error("igemm_conv: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            configured = true;
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(k.nMt * k.nNt), dim3(256), lds, st, k);
+    UDA_LAUNCH_CHECK("igemm_conv");
+    return 0;
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_conv_xf(ConvKArgs& k, int xf, hipStream_t st, bool pipe, size_t tile_bytes) {
+    if (pipe) return xf == 0 ? launch_conv_one<TM, TN, WM, WN, true, 0>(k, st, 2 * tile_bytes) : launch_conv_one<TM, TN, WM, WN, true, 1>(k, st, 2 * tile_bytes);
+    return xf == 0 ? launch_conv_one<TM, TN, WM, WN, false, 0>(k, st, tile_bytes) : launch_conv_one<TM, TN, WM, WN, false, 1>(k, st, tile_bytes);
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -668,6 +701,10 @@ static int launch_conv(ConvKArgs& k, int64_t P, hipStream_t st) {
     k.nNt = uda_cdiv(k.Cout, BN);
     // long K: the pipelined form (two tile images, loads two chunks ahead); short K keeps the lean one (more workgroups per CU)
     static const int pipe_min = getenv("UDA_CONV_PIPE_MIN_K") ? atoi(getenv("UDA_CONV_PIPE_MIN_K")) : 192;
+    // 1x1 without a keep-mask: the lean loader (XF 0: also no transform and no activation - gradient matrices; XF 1: the rest)
+    static const int lean = getenv("UDA_CONV_LEAN") ? atoi(getenv("UDA_CONV_LEAN")) : 1;       // A/B switch
+    const int xf = (lean && k.ksize == 1 && !k.src.mask) ? ((!k.src.scale && k.src.act == ACT_NONE) ? 0 : 1) : -1;
+    if (xf >= 0) return launch_conv_xf<TM, TN, WM, WN>(k, xf, st, k.Ktot >= pipe_min, tile_bytes);
     if (k.Ktot >= pipe_min) {
         auto fn = igemm_conv_kernel<TM, TN, WM, WN, true>;
         if (2 * tile_bytes > 64 * 1024) {                   // beyond the default dynamic-LDS limit: raise it once per device

@@ -822,11 +822,11 @@ extern "C" int uda_conv_fwd(const uda_conv_args_t* a, void* stream) {
     // workgroups with 17 % / no padding
     static const int few_env = getenv("UDA_CONV_FEW") ? atoi(getenv("UDA_CONV_FEW")) : 1;
     int few_w = 0;
-    if (few_env && P > 64 && uda_cdiv(P, 128) <= 192) {
-        const int c192 = uda_cdiv(a->Cout, 192) * 192, c320 = uda_cdiv(a->Cout, 320) * 320;
+    if (few_env && P > 64 && uda_cdiv(P, 128) <= 192 && a->Cout <= 320 && k.Ktot <= 1024) {      // (MobileNetV2's shapes; ResNet-101's wider / longer
+        const int c192 = uda_cdiv(a->Cout, 192) * 192, c320 = uda_cdiv(a->Cout, 320) * 320;       // 1x1 convs stay on the wide-tile kernels: measured)
         const int64_t t192 = uda_cdiv(P, 64) * (c192 / 192), t320 = uda_cdiv(P, 64) * (c320 / 320);
-        if (c192 <= c320 && t192 <= 512) few_w = 192;
-        else if (t320 <= 512) few_w = 320;
+        if (c192 <= c320 && t192 >= 192 && t192 <= 512) few_w = 192;
+        else if (t320 >= 192 && t320 <= 512) few_w = 320;
     }
     const bool few = few_w != 0;
     if (uda_conv_uses_x3(a)) e = launch_conv_x3(k, P, a->x3_src, a->x3_w, st, a->workspace, a->workspace_bytes);

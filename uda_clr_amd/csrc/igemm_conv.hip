@@ -65,8 +65,12 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
         const int64_t p = m0 + lrow + 32 * i;
         pok[i] = p < P;
         const int64_t q = pok[i] ? p : 0;
-        pw[i] = (int)(q % W);
-        ph[i] = (int)((q / W) % H);
+        if (XF < 0) {               // (1x1: no tap leaves the pixel - its coordinates, two 64-bit divisions per row, are not needed)
+            pw[i] = (int)(q % W);
+            ph[i] = (int)((q / W) % H);
+        } else {
+            pw[i] = ph[i] = 0;
+        }
     }
 
     struct Stg {                // one chunk of operand loads in registers + what its staging step needs
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(ConvKArgs a) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int hh = ph[i] + dh, ww = pw[i] + dw;
-            const bool ok = c_kval && pok[i] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const bool ok = XF >= 0 ? (c_kval && pok[i]) : (c_kval && pok[i] && hh >= 0 && hh < H && ww >= 0 && ww < W);
             // buffer loads: an out-of-range offset returns zeros (no branch around the load)
             const int q = (int)(m0 + lrow + 32 * i) + dh * W + dw;
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (q * (int)a.src.ldx + ci) * 4 : OOB, 0, 0));

@@ -919,9 +919,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
             breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             bmask[i] = 0x01010101u;
             if (jok && p < P) {
-                const int w0 = (int)(p % W), h0 = (int)((p / W) % H);
-                const int hh = h0 + dh, ww = w0 + dw;
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                bool in = true;
+                if (a.ksize >= 2) {          // (1x1: the tap is the pixel itself - no coordinates, i.e. no two 64-bit divisions per row and chunk)
+                    const int w0 = (int)(p % W), h0 = (int)((p / W) % H);
+                    const int hh = h0 + dh, ww = w0 + dw;
+                    in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                }
+                if (in) {
                     const int64_t q = p + (int64_t)dh * W + dw;
                     breg[i] = uda_ld4(a.src.x + q * a.src.ldx + ci);
                     if (a.src.mask) bmask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + q * a.src.ldm + ci);

@@ -903,44 +903,48 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradKArgs a) {
 
     float4 areg[APASS], breg[BPASS];
     uint32_t bmask[BPASS];
-    unsigned bok = 0;
+    unsigned bok = 0, aok = 0;
 
     auto issue = [&](int chunk) {
         const int64_t p0 = (int64_t)chunk * WGN_BKP;
+        // every load is unconditional, from a clamped position; what does not exist is zeroed in the staging step (bit i of aok / bok).
+        // Behind bounds tests the loads of a chunk sat in separate basic blocks and the kernel streamed at a third of what its bytes allow.
+        const int64_t plast = P - 1;
+        const int coc = min(co, a.Cout > 4 ? a.Cout - 4 : 0);
+        aok = 0;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int64_t p = p0 + apr + i * ARPP;
-            areg[i] = (p < P && co < a.Cout) ? uda_ld4(a.dy + p * a.lddy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            areg[i] = uda_ld4(a.dy + min(p, plast) * a.lddy + (co < a.Cout ? co : coc));
+            aok |= ((p < P && co < a.Cout) ? 1u : 0u) << i;
         }
         bok = 0;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             const int64_t p = p0 + bpr + i * BRPP;
-            breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            bmask[i] = 0x01010101u;
-            if (jok && p < P) {
-                bool in = true;
-                if (a.ksize >= 2) {          // (1x1: the tap is the pixel itself - no coordinates, i.e. no two 64-bit divisions per row and chunk)
-                    const int w0 = (int)(p % W), h0 = (int)((p / W) % H);
-                    const int hh = h0 + dh, ww = w0 + dw;
-                    in = hh >= 0 && hh < H && ww >= 0 && ww < W;
-                }
-                if (in) {
-                    const int64_t q = p + (int64_t)dh * W + dw;
-                    breg[i] = uda_ld4(a.src.x + q * a.src.ldx + ci);
-                    if (a.src.mask) bmask[i] = *reinterpret_cast<const uint32_t*>(a.src.mask + q * a.src.ldm + ci);
-                    bok |= 1u << i;
-                }
+            bool in = jok && p < P;
+            int64_t q = min(p, plast);
+            if (a.ksize >= 2) {          // (1x1: the tap is the pixel itself - no coordinates, i.e. no two 64-bit divisions per row and chunk)
+                const int w0 = (int)(q % W), h0 = (int)((q / W) % H);
+                const int hh = h0 + dh, ww = w0 + dw;
+                const bool inside = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                in = in && inside;
+                q = inside ? q + (int64_t)dh * W + dw : q;
             }
+            const int cic = jok ? ci : 0;
+            breg[i] = uda_ld4(a.src.x + q * a.src.ldx + cic);
+            bmask[i] = a.src.mask ? *reinterpret_cast<const uint32_t*>(a.src.mask + q * a.src.ldm + cic) : 0x01010101u;
+            bok |= (in ? 1u : 0u) << i;
         }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            const bool oka = (aok >> i) & 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (co + j >= a.Cout) v[j] = 0.f;
+                if (!oka || co + j >= a.Cout) v[j] = 0.f;
             uda_st4(&As[(apr + i * ARPP) * BM + acv], make_float4(v[0], v[1], v[2], v[3]));
         }
         typedef float f32x2 __attribute__((ext_vector_type(2)));       // packed prologue, as in the forward kernels
